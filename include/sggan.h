@@ -1,0 +1,155 @@
+/* sggan.h -- C ABI of the MI355X-native SG-GAN train-step kernels (libsggan.so).
+ *
+ * Drop-in boundary for the hot path of fhfonsecaa/SG-GAN-TF2.
+ * The reference has no FFI layer of its own: its hot path is a chain of stock
+ * TensorFlow/Keras ops called from Python (module.py:208-318, model.py:149-200).
+ * Each entry point below replaces the TF op(s) at the cited reference call site;
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types.
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *     the caller owns all buffers including workspaces; nothing is allocated,
+ *     freed or synchronised inside; calls are stream-ordered on `stream`
+ *     (a hipStream_t passed as void*).
+ *   - activations are NHWC with the channel count padded to a multiple of 8
+ *     (SGG_CPAD); padded channels hold zeros.  dtype selects the storage type
+ *     of activations and packed weights: SGG_F32 (parity path, f32 MFMA) or
+ *     SGG_BF16 (performance path, bf16 MFMA, f32 accumulate).  Parameters,
+ *     gradients of parameters, statistics, logits and losses are always f32.
+ *   - return value: SGG_OK (0) or a negative sgg_status; sgg_strerror() names it.
+ */
+#ifndef SGGAN_H
+#define SGGAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGG_VERSION 100          /* major*10000 + minor*100 + patch */
+#define SGG_CPAD 8               /* activation channel granule */
+
+typedef enum { SGG_OK = 0, SGG_EINVAL = -1, SGG_EUNSUPPORTED = -2, SGG_ELAUNCH = -3, SGG_EWORKSPACE = -4 } sgg_status;
+typedef enum { SGG_F32 = 0, SGG_BF16 = 1 } sgg_dtype;
+typedef enum { SGG_ACT_NONE = 0, SGG_ACT_RELU = 1, SGG_ACT_LRELU = 2, SGG_ACT_TANH = 3 } sgg_act;
+typedef enum { SGG_PAD_ZERO = 0, SGG_PAD_REFLECT = 1 } sgg_pad_mode;
+
+/* Geometry of one convolution  y[n,ho,wo,k] = sum_{r,s,c} xpad[n, ho*stride - pad_t + r, wo*stride - pad_l + s, c] * w[r,s,c,k].
+ * pad_mode ZERO : out-of-range taps read 0 (TF 'SAME' is expressed by the caller as
+ *                 pad_t/pad_l = the LEADING pads; the trailing pad is implied by Ho/Wo).
+ * pad_mode REFLECT: tf.pad(...,"REFLECT") of pad_t (= pad_l) followed by a VALID conv.
+ * C and K are the PADDED channel counts (multiples of SGG_CPAD). */
+typedef struct sgg_conv_desc {
+    int32_t N, H, W, C;      /* conv input  (NHWC)  */
+    int32_t K, R, S;         /* conv output channels, kernel height/width */
+    int32_t stride;          /* 1 or 2 */
+    int32_t pad_t, pad_l;
+    int32_t Ho, Wo;          /* conv output spatial size */
+    int32_t pad_mode;        /* sgg_pad_mode */
+    int32_t dtype;           /* sgg_dtype */
+} sgg_conv_desc;
+
+int sgg_version(void);
+const char* sgg_strerror(int status);
+
+/* ---- weights -------------------------------------------------------------------
+ * Keras kernel (HWIO f32, module.py:211 etc.; for Conv2DTranspose the (kh,kw,out,in)
+ * kernel of module.py:254,258 IS the HWIO kernel of the equivalent conv) ->
+ *   w_fwd  [Kpad][R*S*Cpad]  (K-major rows, reduction contiguous)  used by conv fwd / deconv bwd-data
+ *   w_dgrad[Cpad][R*S*Kpad]                                         used by conv bwd-data / deconv fwd
+ * in `dtype`, zero-filled padding.  Either output may be NULL. */
+int sgg_pack_conv_weights(const float* w_hwio, int R, int S, int C, int K, int Cpad, int Kpad,
+                          int dtype, void* w_fwd, void* w_dgrad, void* stream);
+
+/* ---- conv2d: tf.keras.layers.Conv2D (+ tf.pad REFLECT) ---- module.py:210-216,230-232,236,240,262-264,284-311
+ * fwd: y = act(conv(x) + bias);  bias may be NULL; bias has Kpad f32 entries. */
+int sgg_conv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
+                   void* y, int act, float leak, void* stream);
+/* bwd_data: dx = conv^T(dy) including the MirrorPadGrad fold for REFLECT (gen_tape.gradient, model.py:196). */
+int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, void* stream);
+/* bwd_weight: dw_hwio[R][S][C_real][K_real] f32, overwritten (accumulate=0) or added to (accumulate=1: a network
+ * applied twice in one step, model.py:186-187).  ws: sgg_conv2d_bwd_weight_workspace() bytes. */
+size_t sgg_conv2d_bwd_weight_workspace(const sgg_conv_desc* d);
+int sgg_conv2d_bwd_weight(const sgg_conv_desc* d, const void* x, const void* dy, float* dw_hwio,
+                          int C_real, int K_real, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- deconv2d: tf.keras.layers.Conv2DTranspose(3x3, s2, 'same') ---- module.py:254,258
+ * `d` describes the EQUIVALENT FORWARD CONV whose input is the deconv OUTPUT:
+ *   (d->N,H,W,C) = deconv output, (d->Ho,Wo,K) = deconv input, pad_t/pad_l = TF SAME leading pads of that conv.
+ * fwd: y[N,H,W,C] = act(conv^T(x[N,Ho,Wo,K]) + bias[C]). */
+int sgg_deconv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w_dgrad, const float* bias,
+                     void* y, int act, float leak, void* stream);
+int sgg_deconv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w_fwd, void* dx, void* stream);
+/* dw has the Keras transpose-kernel layout [R][S][C_real(out)][K_real(in)]. */
+int sgg_deconv2d_bwd_weight(const sgg_conv_desc* d, const void* x, const void* dy, float* dw,
+                            int C_real, int K_real, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* bias gradient: db[c] (+)= sum_p dy[p][c], c < C_real (f32).  ws >= sgg_bias_grad_workspace(P, C) bytes. */
+size_t sgg_bias_grad_workspace(int64_t P, int C);
+int sgg_bias_grad(const void* dy, float* db, int64_t P, int C, int C_real, int accumulate, int dtype,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* ---- instance_norm: tfa.layers.InstanceNormalization ---- module.py:212,216,233,...,308 (spec by name: ops.py:13-22)
+ * y = act(gamma*(x-mean)*rstd + beta) (+ residual, added AFTER act; module.py:217 uses act NONE).
+ * stats[N][C][2] = (mean, rstd) f32 is written by fwd and read by bwd.
+ * ws >= sgg_instnorm_workspace(N, HW, C) bytes. */
+size_t sgg_instnorm_workspace(int N, int64_t HW, int C);
+int sgg_instnorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* y,
+                     float* stats, int N, int64_t HW, int C, float eps, int act, float leak, int dtype,
+                     void* ws, size_t ws_bytes, void* stream);
+/* dx = d/dx of the above given dy (w.r.t. the post-activation output); dgamma/dbeta[C_real] f32 overwritten or
+ * (accumulate=1) added to.  gamma/beta/stats are indexed over the padded C. */
+int sgg_instnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats,
+                     void* dx, float* dgamma, float* dbeta, int N, int64_t HW, int C, int C_real, int accumulate,
+                     int act, float leak, int dtype, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- lrelu / relu / tanh: tf.keras.layers.LeakyReLU / Activation ---- module.py:213,265,285 (ops.py:36-37) */
+int sgg_act_fwd(const void* x, void* y, int64_t n, int act, float leak, int dtype, void* stream);
+/* dx = dy * act'(.) evaluated from the OUTPUT y (relu/lrelu: sign of y; tanh: 1-y^2). */
+int sgg_act_bwd(const void* dy, const void* y, void* dx, int64_t n, int act, float leak, int dtype, void* stream);
+/* out = a + b (residual join of gradients). */
+int sgg_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+
+/* ---- semantic mask over the adversarial map ---- module.py:312-314
+ * out[n,i,j] = sum_{c<C_real} h4[n,i',j',c] * mask[n,i,j,c];  h4 is (N,hh,hw,Cpad) in dtype, mask (N,mh,mw,C_real) f32;
+ * (hh,hw) == (mh,mw), or (1,1) broadcast over the mask grid (the 128x128 reference case).  out f32 (N,mh,mw). */
+int sgg_mask_reduce_fwd(const void* h4, const float* mask, float* out, int N, int hh, int hw, int mh, int mw,
+                        int C_real, int Cpad, int dtype, void* stream);
+int sgg_mask_reduce_bwd(const float* dout, const float* mask, void* dh4, int N, int hh, int hw, int mh, int mw,
+                        int C_real, int Cpad, int dtype, void* stream);
+
+/* ---- losses ---- model.py:149-166
+ * BCE-with-logits against a constant label, global mean:  *loss (+)= weight*mean(...);
+ * dlogits[i] (+)= weight*gscale*(sigmoid(x_i)-label)/n.  accumulate bit0: add into *loss; bit1: add into dlogits. */
+int sgg_bce_logits(const float* logits, int64_t n, float label, float weight, float gscale, float* loss, float* dlogits,
+                   int accumulate, void* stream);
+/* L1: *loss (+)= weight*mean_{p,c<C_real}|a-b|;  db = -weight*gscale*sign(a-b)/(P*C_real) (0 in padded channels). */
+int sgg_l1_loss(const void* a, const void* b, int64_t P, int C_real, int Cpad, float weight, float gscale, float* loss,
+                void* db, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
+size_t sgg_l1_loss_workspace(int64_t P, int Cpad);
+
+/* ---- optimizer: tf.keras.optimizers.Adam.apply_gradients ---- model.py:199-200,205-207
+ * Keras form, over one flat f32 buffer:  m=b1*m+(1-b1)*g; v=b2*v+(1-b2)*g^2;
+ * theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps);   g is first multiplied by grad_scale (1/world for DP). */
+int sgg_adam(float* theta, const float* g, float* m, float* v, int64_t n, int t, float lr, float beta1, float beta2,
+             float eps, float grad_scale, void* stream);
+
+/* ---- data side of the step ----
+ * segment_class.py:60-70,95-97: colour -> class index, bit exact.  rgb: uint8 [n_pixels][channels>=3]. */
+int sgg_seg_class_map(const uint8_t* rgb, int channels, int64_t n_pixels, uint8_t* out, void* stream);
+/* host-side copy of the kernel's colour table (keys = R<<16|G<<8|B); returns the entry count (21). No GPU needed. */
+int sgg_seg_class_table(uint32_t* keys_host, uint8_t* vals_host, int capacity);
+/* utils.py:158-165 + :197-199 (deviation D1): one-hot of the align-corners nearest resample of the
+ * class-index map:  mask[n,i,j,c] = (idx[n, round(i*(H-1)/(oh-1)), round(j*(W-1)/(ow-1))] == c). */
+int sgg_onehot_resample(const uint8_t* idx, float* mask, int N, int H, int W, int oh, int ow, int n_classes, void* stream);
+/* f32 [P][Cs] -> dtype [P][Cd] with zero fill (Cd >= Cs), and back (drops padded channels). */
+int sgg_pad_channels(const float* src, void* dst, int64_t P, int Cs, int Cd, int dtype, void* stream);
+int sgg_unpad_channels(const void* src, float* dst, int64_t P, int Cs, int Cd, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGGAN_H */

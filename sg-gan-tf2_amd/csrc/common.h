@@ -1,0 +1,95 @@
+// common.h -- shared device/host helpers for libsggan.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/sggan.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+#define SGG_WAVE 64
+
+// 16-byte chunk <-> floats.  VEC = elements per 16-byte chunk (4 for f32, 8 for bf16).
+template <typename T> struct ET;
+template <> struct ET<float> {
+    static constexpr int VEC = 4;
+    __device__ static inline void unpack(const u32x4& c, float* f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(c[i]);
+    }
+    __device__ static inline u32x4 pack(const float* f) {
+        u32x4 c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = __float_as_uint(f[i]);
+        return c;
+    }
+};
+template <> struct ET<bf16> {
+    static constexpr int VEC = 8;
+    __device__ static inline void unpack(const u32x4& c, float* f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(c[i] << 16);
+            f[2 * i + 1] = __uint_as_float(c[i] & 0xffff0000u);
+        }
+    }
+    __device__ static inline u32x4 pack(const float* f) {
+        u32x4 c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16 lo = (bf16)f[2 * i], hi = (bf16)f[2 * i + 1];   // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+            c[i] = (uint32_t)__builtin_bit_cast(uint16_t, lo) | ((uint32_t)__builtin_bit_cast(uint16_t, hi) << 16);
+        }
+        return c;
+    }
+};
+
+__device__ inline u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ inline void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
+__device__ inline u32x4 zero16() { u32x4 z = {0u, 0u, 0u, 0u}; return z; }
+
+__device__ inline float act_apply(float v, int act, float leak) {
+    switch (act) {
+        case SGG_ACT_RELU: return v > 0.f ? v : 0.f;
+        case SGG_ACT_LRELU: return v > 0.f ? v : leak * v;
+        case SGG_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+// derivative evaluated from the pre-activation (relu/lrelu) -- sign only
+__device__ inline float act_grad_from_pre(float pre, int act, float leak) {
+    switch (act) {
+        case SGG_ACT_RELU: return pre > 0.f ? 1.f : 0.f;
+        case SGG_ACT_LRELU: return pre > 0.f ? 1.f : leak;
+        default: return 1.f;
+    }
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// exact n/d for 0 <= n < 2^31 via (n*m) >> (31+s)   (Hacker's Delight round-up magic)
+struct FastDiv {
+    uint32_t m, s, d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    f.s = s;
+    f.m = (uint32_t)(((1ull << (31 + s)) / d) + 1ull);
+    return f;
+}
+__device__ inline uint32_t fdiv(uint32_t n, const FastDiv& f) {
+    return (uint32_t)(((uint64_t)n * f.m) >> (31 + f.s));
+}
+
+static inline int sgg_check_launch() { return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ELAUNCH; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -1,0 +1,628 @@
+// conv.hip -- implicit-GEMM convolution on gfx950 MFMA tiles.
+//
+// Replaces: tf.keras.layers.Conv2D / Conv2DTranspose and the
+// tf.pad(...,"REFLECT") in front of them (module.py:210-216,230-264,284-311) and their
+// gradients (gen_tape/disc_tape.gradient, model.py:196-197).
+//
+// Three GEMM kernels, all NHWC with channels padded to 8 so every gather is a 16-byte chunk:
+//   conv_gemm<FWD>   y[pixel][k]   = sum_{tap,c} x~[pixel,tap][c] * Wf[k][tap,c]       (gather over x)
+//   conv_gemm<DGRAD> dx[pixel][c]  = sum_{tap,k} dy[pixel,tap][k] * Wd[c][tap,k]       (transposed gather; the
+//                    stride-2 case is split into stride^2 output-parity classes so each block only visits the
+//                    taps that hit its pixels; REFLECT folds the mirrored border gradients in the gather)
+//   conv_wgrad       dW[tap,c][k]  = sum_{pixel} x~[pixel,tap][c] * dy[pixel][k]        (reduction over pixels,
+//                    operands transposed on the fly with ds_read_b64_tr_b16; split over pixel ranges into f32
+//                    slabs that a second kernel sums in fixed order -> deterministic)
+// Conv2DTranspose forward IS conv_gemm<DGRAD> of the equivalent conv (plus bias), its data gradient IS
+// conv_gemm<FWD>, its weight gradient IS conv_wgrad with the operand roles swapped.
+//
+// Tile: 256 threads = 4 waves; LDS rows are 128-byte K-slices (64 bf16 / 32 f32) XOR-swizzled on the 16-byte
+// chunk index so the ds_read_b128 fragment reads are bank-conflict free; MFMA 16x16x32 bf16 (or 16x16x4 f32 on
+// the parity path, consuming the same 16-byte fragments with a k-permutation that A and B share).
+// The weight fragment is the MFMA A operand and the pixel fragment the B operand, so the accumulator holds
+// D[cout][pixel]: each lane owns 4 consecutive output channels of one pixel = one 8/16-byte NHWC store.
+#include "common.h"
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+struct ConvArgs {
+    const char* src;     // FWD: x (N,H,W,C)    DGRAD: dy (N,Ho,Wo,K)
+    const char* wmat;    // FWD: [K][R*S*C]     DGRAD: [C][R*S*K]
+    const float* bias;   // per destination channel or nullptr
+    char* dst;           // FWD: y (N,Ho,Wo,K)  DGRAD: dx (N,H,W,C)
+    int N, H, W, C, K, R, S, stride, pad_t, pad_l, Ho, Wo, reflect;
+    int act;
+    float leak;
+};
+
+template <typename T>
+__device__ inline u32x4 chunk_add(const u32x4& a, const u32x4& b) {
+    float fa[ET<T>::VEC], fb[ET<T>::VEC];
+    ET<T>::unpack(a, fa);
+    ET<T>::unpack(b, fb);
+#pragma unroll
+    for (int i = 0; i < ET<T>::VEC; ++i) fa[i] += fb[i];
+    return ET<T>::pack(fa);
+}
+
+// candidate padded-grid coordinates that reflect onto h (MirrorPadGrad preimages); returns count, fills j[3]
+__device__ inline int reflect_preimages(int h, int H, int p, int* j) {
+    int n = 0;
+    j[n++] = h + p;
+    if (h >= 1 && h <= p) j[n++] = p - h;
+    if (h >= H - 1 - p && h <= H - 2) j[n++] = p + 2 * (H - 1) - h;
+    return n;
+}
+
+template <typename T, int MODE, int BM, int BN, int WGM>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
+    constexpr int VEC = ET<T>::VEC;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int WGN = 4 / WGM;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int MI = WM / 16, NI = WN / 16;
+    constexpr int PA = BM / 32;                 // pixel-tile chunks per thread
+    constexpr int QA = (BN + 31) / 32;          // weight-tile chunks per thread
+    static_assert(BM % 32 == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sP = smem;                    // [2][BM][128]
+    char* sQ = smem + 2 * BM * 128;     // [2][BN][128]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int st = (MODE == MODE_DGRAD) ? a.stride : 1;      // tap-enumeration step
+    const int ph = (MODE == MODE_DGRAD) ? (int)blockIdx.z / a.stride : 0;
+    const int pw = (MODE == MODE_DGRAD) ? (int)blockIdx.z % a.stride : 0;
+    const int nr = ph < a.R ? (a.R - ph + st - 1) / st : 0;  // taps of this class along r / s
+    const int ns = pw < a.S ? (a.S - pw + st - 1) / st : 0;
+    const int SC = (MODE == MODE_FWD) ? a.C : a.K;           // reduction channels (source tensor)
+    const int DC = (MODE == MODE_FWD) ? a.K : a.C;           // destination channels
+    const int cpv = SC / VEC;                                // 16-byte chunks per tap
+    const int wrow = a.R * a.S * SC;                         // weight row length (elements)
+
+    // ---- destination pixel space of this block ----
+    int hbase = 0, wbase = 0, Hc, Wc;
+    if (MODE == MODE_FWD) { Hc = a.Ho; Wc = a.Wo; }
+    else {
+        hbase = ((ph - a.pad_t) % st + st) % st;
+        wbase = ((pw - a.pad_l) % st + st) % st;
+        Hc = hbase < a.H ? (a.H - hbase + st - 1) / st : 0;
+        Wc = wbase < a.W ? (a.W - wbase + st - 1) / st : 0;
+    }
+    const int M = a.N * Hc * Wc;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (m0 >= M) return;                                     // whole block outside this class (uniform)
+
+    // per-thread staging rows: row = (tid>>3) + 32*i, chunk column c = tid&7
+    const int cc0 = tid & 7;
+    int rn[PA], rh[PA], rw[PA];                              // image, and the row's h/w anchor
+    bool rborder[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        int m = m0 + (tid >> 3) + 32 * i;
+        rborder[i] = false;
+        if (m < M) {
+            int n = m / (Hc * Wc), rem = m - n * (Hc * Wc);
+            int hp = rem / Wc, wp = rem - hp * Wc;
+            rn[i] = n;
+            if (MODE == MODE_FWD) { rh[i] = hp * a.stride - a.pad_t; rw[i] = wp * a.stride - a.pad_l; }
+            else {
+                int h = hbase + st * hp, w = wbase + st * wp;
+                if (a.reflect) {                             // stride 1: keep destination coords; fold in the gather
+                    rh[i] = h; rw[i] = w;
+                    int p = a.pad_t;
+                    rborder[i] = (h >= 1 && h <= p) || (h >= a.H - 1 - p && h <= a.H - 2) ||
+                                 (w >= 1 && w <= p) || (w >= a.W - 1 - p && w <= a.W - 2);
+                } else { rh[i] = (h + a.pad_t - ph) / st; rw[i] = (w + a.pad_l - pw) / st; }
+            }
+        } else rn[i] = -1;
+    }
+
+    // tap iterator of this thread's chunk column (shared by all its rows)
+    int t_cc, t_ri, t_si;
+    { int ti = cc0 / cpv; t_cc = cc0 - ti * cpv; t_ri = ns ? ti / ns : nr; t_si = ns ? ti - t_ri * ns : 0; }
+    const int ktiles = (nr * ns * cpv + 7) / 8;
+
+    u32x4 regP[PA], regQ[QA];
+
+    auto load_tile = [&]() {
+        const bool tapok = t_ri < nr;
+        const int r = ph + st * t_ri, s = pw + st * t_si;
+        // weights
+#pragma unroll
+        for (int i = 0; i < QA; ++i) {
+            int row = (tid >> 3) + 32 * i, dc = n0 + row;
+            regQ[i] = zero16();
+            if (tapok && row < BN && dc < DC)
+                regQ[i] = ld16(a.wmat + ((size_t)dc * wrow + (size_t)(r * a.S + s) * SC + t_cc * VEC) * ES);
+        }
+        // pixels
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            regP[i] = zero16();
+            if (!tapok || rn[i] < 0) continue;
+            if (MODE == MODE_FWD) {
+                int hi = rh[i] + r, wi = rw[i] + s;
+                bool ok = true;
+                if (a.reflect) {
+                    hi = hi < 0 ? -hi : (hi >= a.H ? 2 * (a.H - 1) - hi : hi);
+                    wi = wi < 0 ? -wi : (wi >= a.W ? 2 * (a.W - 1) - wi : wi);
+                } else ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                if (ok) regP[i] = ld16(a.src + (((size_t)rn[i] * a.H + hi) * a.W + wi) * SC * ES + t_cc * 16);
+            } else if (!a.reflect) {
+                int ho = rh[i] - t_ri, wo = rw[i] - t_si;
+                if ((unsigned)ho < (unsigned)a.Ho && (unsigned)wo < (unsigned)a.Wo)
+                    regP[i] = ld16(a.src + (((size_t)rn[i] * a.Ho + ho) * a.Wo + wo) * SC * ES + t_cc * 16);
+            } else if (!rborder[i]) {
+                int ho = rh[i] + a.pad_t - r, wo = rw[i] + a.pad_l - s;
+                if ((unsigned)ho < (unsigned)a.Ho && (unsigned)wo < (unsigned)a.Wo)
+                    regP[i] = ld16(a.src + (((size_t)rn[i] * a.Ho + ho) * a.Wo + wo) * SC * ES + t_cc * 16);
+            } else {                                         // MirrorPadGrad fold: sum over reflected preimages
+                int jh[3], jw[3];
+                int nh = reflect_preimages(rh[i], a.H, a.pad_t, jh);
+                int nw = reflect_preimages(rw[i], a.W, a.pad_l, jw);
+                bool first = true;
+                for (int ia = 0; ia < nh; ++ia)
+                    for (int ib = 0; ib < nw; ++ib) {
+                        int ho = jh[ia] - r, wo = jw[ib] - s;
+                        if ((unsigned)ho < (unsigned)a.Ho && (unsigned)wo < (unsigned)a.Wo) {
+                            u32x4 v = ld16(a.src + (((size_t)rn[i] * a.Ho + ho) * a.Wo + wo) * SC * ES + t_cc * 16);
+                            regP[i] = first ? v : chunk_add<T>(regP[i], v);
+                            first = false;
+                        }
+                    }
+            }
+        }
+        // advance the tap iterator by one K-tile (8 chunks)
+        t_cc += 8;
+        while (t_cc >= cpv) { t_cc -= cpv; if (++t_si == ns) { t_si = 0; ++t_ri; } }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            int row = (tid >> 3) + 32 * i;
+            st16(sP + (buf * BM + row) * 128 + ((cc0 ^ ((row >> 1) & 7)) << 4), regP[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < QA; ++i) {
+            int row = (tid >> 3) + 32 * i;
+            if (row < BN) st16(sQ + (buf * BN + row) * 128 + ((cc0 ^ ((row >> 1) & 7)) << 4), regQ[i]);
+        }
+    };
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4, fsw = frow >> 1;   // fragment row / k-chunk / swizzle key
+
+    if (ktiles > 0) { load_tile(); store_tile(0); }
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ktiles) load_tile();
+        const char* bP = sP + (buf * BM + wm * WM + frow) * 128;
+        const char* bQ = sQ + (buf * BN + wn * WN + frow) * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int off = (((fq + 4 * kk) ^ fsw) << 4);
+            u32x4 fp[MI], fw[NI];
+#pragma unroll
+            for (int j = 0; j < MI; ++j) fp[j] = ld16(bP + j * 16 * 128 + off);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) fw[i] = ld16(bQ + i * 16 * 128 + off);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fw[i]), __builtin_bit_cast(bf16x8, fp[j]), acc[i][j], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                __uint_as_float(fw[i][e]), __uint_as_float(fp[j][e]), acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+        if (kt + 1 < ktiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds D[cout = 4*fq + e][pixel = frow] of each 16x16 tile ----
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+        int m = m0 + wm * WM + j * 16 + frow;
+        if (m >= M) continue;
+        size_t dpix;
+        if (MODE == MODE_FWD) dpix = (size_t)m;
+        else {
+            int n = m / (Hc * Wc), rem = m - n * (Hc * Wc);
+            int hp = rem / Wc, wp = rem - hp * Wc;
+            dpix = ((size_t)n * a.H + hbase + st * hp) * a.W + wbase + st * wp;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int dc = n0 + wn * WN + i * 16 + fq * 4;
+            if (dc >= DC) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = acc[i][j][e] + (a.bias ? a.bias[dc + e] : 0.f);
+                v[e] = act_apply(t, a.act, a.leak);
+            }
+            T* o = reinterpret_cast<T*>(a.dst) + dpix * DC + dc;
+            if constexpr (sizeof(T) == 2) {
+                bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                *reinterpret_cast<bf16x4*>(o) = pk;
+            } else {
+                *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// weight gradient
+// -------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const char* x;       // (N,H,W,C)  gathered operand
+    const char* dy;      // (N,Ho,Wo,K)
+    float* ws;           // [splits][R*S*C][K] f32 slabs
+    int N, H, W, C, K, R, S, stride, pad_t, pad_l, Ho, Wo, reflect;
+    int P, pix_per_split;
+    FastDiv dHW, dW;     // divide by Ho*Wo, Wo
+};
+
+__device__ inline int wg_swz(int chunk, int row, int nchunks) {
+    int f = (row & 3) | (((row >> 3) & 1) << 2);
+    return chunk ^ ((f << 1) & (nchunks - 1));
+}
+
+template <typename T, int BMW, int BNW, int WGM>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    constexpr int VEC = ET<T>::VEC;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int BKP = 32;                               // pixels per K-step
+    constexpr int WGN = 4 / WGM;
+    constexpr int WMW = BMW / WGM, WNW = BNW / WGN;
+    constexpr int MI = WMW / 16, NI = WNW / 16;
+    constexpr int NCX = BMW / VEC, NCD = BNW / VEC;       // 16-byte chunks per tile row
+    constexpr int RPX = 256 / NCX, RPD = 256 / NCD;       // pixel rows covered per pass
+    constexpr int PX = (BKP + RPX - 1) / RPX, PD = (BKP + RPD - 1) / RPD;
+    constexpr int XP = BMW * ES, DP = BNW * ES;           // row pitch (bytes)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sX = smem;                       // [2][BKP][XP]
+    char* sD = smem + 2 * BKP * XP;        // [2][BKP][DP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int Mrows = a.R * a.S * a.C;
+    const int m0 = blockIdx.x * BMW, n0 = blockIdx.y * BNW;
+    const int pbeg = blockIdx.z * a.pix_per_split;
+    const int pend = min(a.P, pbeg + a.pix_per_split);
+
+    // fixed chunk column of this thread in each tile
+    const int jx = tid % NCX, rx = tid / NCX;
+    const int jd = tid % NCD, rd = tid / NCD;
+    const int mrow = m0 + jx * VEC;
+    const bool xcol_ok = mrow < Mrows;
+    const int tap = xcol_ok ? mrow / a.C : 0, c0 = mrow - tap * a.C;
+    const int tr = tap / a.S, ts = tap - tr * a.S;
+    const bool dcol_ok = (n0 + jd * VEC) < a.K;
+
+    u32x4 regX[PX], regD[PD];
+    auto load_tile = [&](int p0) {
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            int prow = rx + i * RPX, p = p0 + prow;
+            regX[i] = zero16();
+            if (prow < BKP && xcol_ok && p < pend) {
+                uint32_t n = fdiv((uint32_t)p, a.dHW), rem = (uint32_t)p - n * a.dHW.d;
+                uint32_t ho = fdiv(rem, a.dW), wo = rem - ho * a.dW.d;
+                int hi = (int)ho * a.stride - a.pad_t + tr, wi = (int)wo * a.stride - a.pad_l + ts;
+                bool ok = true;
+                if (a.reflect) {
+                    hi = hi < 0 ? -hi : (hi >= a.H ? 2 * (a.H - 1) - hi : hi);
+                    wi = wi < 0 ? -wi : (wi >= a.W ? 2 * (a.W - 1) - wi : wi);
+                } else ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                if (ok) regX[i] = ld16(a.x + ((((size_t)n * a.H + hi) * a.W + wi) * a.C + c0) * ES);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PD; ++i) {
+            int prow = rd + i * RPD, p = p0 + prow;
+            regD[i] = zero16();
+            if (prow < BKP && dcol_ok && p < pend)
+                regD[i] = ld16(a.dy + ((size_t)p * a.K + n0 + jd * VEC) * ES);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            int prow = rx + i * RPX;
+            if (prow < BKP) st16(sX + (buf * BKP + prow) * XP + (wg_swz(jx, prow, NCX) << 4), regX[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < PD; ++i) {
+            int prow = rd + i * RPD;
+            if (prow < BKP) st16(sD + (buf * BKP + prow) * DP + (wg_swz(jd, prow, NCD) << 4), regD[i]);
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, u = lane & 15;
+    const int ksteps = pend > pbeg ? (pend - pbeg + BKP - 1) / BKP : 0;
+    if (ksteps > 0) { load_tile(pbeg); store_tile(0); }
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < ksteps) load_tile(pbeg + (ks + 1) * BKP);
+        const char* bX = sX + buf * BKP * XP;
+        const char* bD = sD + buf * BKP * DP;
+        if constexpr (sizeof(T) == 2) {
+            // transposing LDS read: 16-lane group g fetches pixels 8g..8g+7 (two 4-row blocks) x 16 columns;
+            // lane u supplies row (u>>2), columns 4*(u&3)..+3 and receives column u of the 4 rows.
+            const int q = u >> 2, pp = u & 3;
+            bf16x8 fa[MI], fb[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                int col = wm * WMW + i * 16 + 4 * pp;          // element column in the X tile
+                int ch = col >> 3, sub = (col & 7) * 2;
+                int r0 = 8 * g + q, r1 = r0 + 4;
+                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(bX + r0 * XP + (wg_swz(ch, r0, NCX) << 4) + sub));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(bX + r1 * XP + (wg_swz(ch, r1, NCX) << 4) + sub));
+                fa[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                int col = wn * WNW + j * 16 + 4 * pp;
+                int ch = col >> 3, sub = (col & 7) * 2;
+                int r0 = 8 * g + q, r1 = r0 + 4;
+                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(bD + r0 * DP + (wg_swz(ch, r0, NCD) << 4) + sub));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(bD + r1 * DP + (wg_swz(ch, r1, NCD) << 4) + sub));
+                fb[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s4 = 0; s4 < BKP / 4; ++s4) {
+                int row = 4 * s4 + g;
+                float fa[MI], fb[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    int col = wm * WMW + i * 16 + u;
+                    fa[i] = *reinterpret_cast<const float*>(bX + row * XP + (wg_swz(col >> 2, row, NCX) << 4) + (col & 3) * 4);
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    int col = wn * WNW + j * 16 + u;
+                    fb[j] = *reinterpret_cast<const float*>(bD + row * DP + (wg_swz(col >> 2, row, NCD) << 4) + (col & 3) * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (ks + 1 < ksteps) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // D[row = 4g+e -> (tap,c)][col = u -> k]
+    float* slab = a.ws + (size_t)blockIdx.z * Mrows * a.K;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            int k = n0 + wn * WNW + j * 16 + u;
+            if (k >= a.K) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int mr = m0 + wm * WMW + i * 16 + g * 4 + e;
+                if (mr < Mrows) slab[(size_t)mr * a.K + k] = acc[i][j][e];
+            }
+        }
+}
+
+// dw[tap][c<Cr][k<Kr] (+)= sum_split ws[split][tap*C + c][k]   (fixed order -> deterministic)
+__global__ void wgrad_reduce_kernel(const float* ws, float* dw, int taps, int C, int K, int Cr, int Kr, int splits, int accumulate) {
+    int64_t total = (int64_t)taps * Cr * Kr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int k = (int)(i % Kr);
+        int64_t t = i / Kr;
+        int c = (int)(t % Cr), tap = (int)(t / Cr);
+        size_t off = ((size_t)tap * C + c) * K + k, slab = (size_t)taps * C * K;
+        float s = 0.f;
+        for (int sp = 0; sp < splits; ++sp) s += ws[sp * slab + off];
+        dw[i] = accumulate ? dw[i] + s : s;
+    }
+}
+
+// HWIO f32 -> [Kpad][R*S*Cpad] and [Cpad][R*S*Kpad] in dtype T, zero padded
+template <typename T>
+__global__ void pack_weights_kernel(const float* w, int taps, int C, int K, int Cpad, int Kpad, T* wf, T* wd) {
+    int64_t total = (int64_t)taps * Cpad * Kpad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int k = (int)(i % Kpad);
+        int64_t t = i / Kpad;
+        int c = (int)(t % Cpad), tap = (int)(t / Cpad);
+        float v = (c < C && k < K) ? w[((size_t)tap * C + c) * K + k] : 0.f;
+        if (wf) wf[((size_t)k * taps + tap) * Cpad + c] = (T)v;
+        if (wd) wd[((size_t)c * taps + tap) * Kpad + k] = (T)v;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+static bool desc_ok(const sgg_conv_desc* d) {
+    if (!d) return false;
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->R <= 0 || d->S <= 0) return false;
+    if (d->C <= 0 || d->K <= 0 || d->C % SGG_CPAD || d->K % SGG_CPAD) return false;
+    if (d->stride != 1 && d->stride != 2) return false;
+    if (d->dtype != SGG_F32 && d->dtype != SGG_BF16) return false;
+    if (d->pad_mode == SGG_PAD_REFLECT) {
+        if (d->stride != 1 || d->pad_t != d->pad_l || d->pad_t >= d->H || d->pad_t >= d->W) return false;
+        if (d->Ho != d->H + 2 * d->pad_t - d->R + 1 || d->Wo != d->W + 2 * d->pad_l - d->S + 1) return false;
+    } else if (d->pad_mode != SGG_PAD_ZERO) return false;
+    if (d->pad_t < 0 || d->pad_l < 0) return false;
+    // every output window must start inside the (leading-)padded input
+    if ((int64_t)(d->Ho - 1) * d->stride - d->pad_t >= d->H || (int64_t)(d->Wo - 1) * d->stride - d->pad_l >= d->W) return false;
+    if ((int64_t)d->N * d->H * d->W >= (1ll << 31) / 2 || (int64_t)d->N * d->Ho * d->Wo >= (1ll << 31) / 2) return false;
+    return true;
+}
+
+static ConvArgs make_args(const sgg_conv_desc* d, const void* src, const void* w, const float* bias, void* dst, int act, float leak) {
+    ConvArgs a;
+    a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S; a.stride = d->stride;
+    a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.reflect = d->pad_mode == SGG_PAD_REFLECT;
+    a.act = act; a.leak = leak;
+    return a;
+}
+
+template <typename T, int MODE, int BM, int BN, int WGM>
+static int launch_gemm_cfg(const ConvArgs& a, int64_t Mmax, int DC, int classes, hipStream_t s) {
+    constexpr size_t lds = 2 * (BM + BN) * 128;
+    auto kern = conv_gemm_kernel<T, MODE, BM, BN, WGM>;
+    static bool attr_done = false;
+    if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+    dim3 grid((unsigned)((Mmax + BM - 1) / BM), (unsigned)((DC + BN - 1) / BN), (unsigned)classes);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    return sgg_check_launch();
+}
+
+template <typename T, int MODE>
+static int launch_gemm(const ConvArgs& a, hipStream_t s) {
+    int DC, classes;
+    int64_t Mmax;
+    if (MODE == MODE_FWD) { DC = a.K; classes = 1; Mmax = (int64_t)a.N * a.Ho * a.Wo; }
+    else {
+        DC = a.C; classes = a.stride * a.stride;
+        Mmax = (int64_t)a.N * ((a.H + a.stride - 1) / a.stride) * ((a.W + a.stride - 1) / a.stride);
+    }
+    if (DC >= 128) return launch_gemm_cfg<T, MODE, 128, 128, 2>(a, Mmax, DC, classes, s);
+    if (DC > 16) return launch_gemm_cfg<T, MODE, 128, 64, 4>(a, Mmax, DC, classes, s);
+    return launch_gemm_cfg<T, MODE, 256, 16, 4>(a, Mmax, DC, classes, s);
+}
+
+template <typename T, int BMW, int BNW, int WGM>
+static int launch_wgrad_cfg(WgradArgs& a, int splits, hipStream_t s) {
+    constexpr size_t lds = 2 * 32 * (BMW + BNW) * sizeof(T);
+    auto kern = conv_wgrad_kernel<T, BMW, BNW, WGM>;
+    static bool attr_done = false;
+    if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+    int Mrows = a.R * a.S * a.C;
+    dim3 grid((unsigned)((Mrows + BMW - 1) / BMW), (unsigned)((a.K + BNW - 1) / BNW), (unsigned)splits);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    return sgg_check_launch();
+}
+
+static int wgrad_splits(const sgg_conv_desc* d) {
+    int64_t P = (int64_t)d->N * d->Ho * d->Wo;
+    int bnw = d->K >= 128 ? 128 : (d->K > 16 ? 64 : 16);
+    int64_t tiles = (int64_t)((d->R * d->S * d->C + 127) / 128) * ((d->K + bnw - 1) / bnw);
+    int64_t want = (1024 + tiles - 1) / tiles;                 // ~4 blocks per CU
+    int64_t maxs = (P + 255) / 256;                            // >= 256 pixels per split
+    int64_t sp = want < maxs ? want : maxs;
+    if (sp < 1) sp = 1;
+    if (sp > 64) sp = 64;
+    return (int)sp;
+}
+
+template <typename T>
+static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, float* dw, int Cr, int Kr, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+    WgradArgs a;
+    a.x = (const char*)x; a.dy = (const char*)dy; a.ws = (float*)ws;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S; a.stride = d->stride;
+    a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.reflect = d->pad_mode == SGG_PAD_REFLECT;
+    a.P = d->N * d->Ho * d->Wo;
+    int splits = wgrad_splits(d);
+    a.pix_per_split = (int)align_up((size_t)((a.P + splits - 1) / splits), 32);
+    splits = (a.P + a.pix_per_split - 1) / a.pix_per_split;
+    a.dHW = make_fastdiv((uint32_t)(d->Ho * d->Wo)); a.dW = make_fastdiv((uint32_t)d->Wo);
+    size_t need = (size_t)splits * d->R * d->S * d->C * d->K * sizeof(float);
+    if (ws_bytes < need || !ws) return SGG_EWORKSPACE;
+    int rc;
+    if (d->K >= 128) rc = launch_wgrad_cfg<T, 128, 128, 2>(a, splits, s);
+    else if (d->K > 16) rc = launch_wgrad_cfg<T, 128, 64, 4>(a, splits, s);
+    else rc = launch_wgrad_cfg<T, 128, 16, 4>(a, splits, s);
+    if (rc) return rc;
+    int64_t total = (int64_t)d->R * d->S * Cr * Kr;
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, dw, d->R * d->S, d->C, d->K, Cr, Kr, splits, accumulate);
+    return sgg_check_launch();
+}
+
+extern "C" {
+
+int sgg_pack_conv_weights(const float* w, int R, int S, int C, int K, int Cpad, int Kpad, int dtype, void* wf, void* wd, void* stream) {
+    if (!w || R <= 0 || S <= 0 || C <= 0 || K <= 0 || Cpad < C || Kpad < K || Cpad % SGG_CPAD || Kpad % SGG_CPAD) return SGG_EINVAL;
+    int64_t total = (int64_t)R * S * Cpad * Kpad;
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    if (dtype == SGG_BF16) hipLaunchKernelGGL(pack_weights_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, R * S, C, K, Cpad, Kpad, (bf16*)wf, (bf16*)wd);
+    else if (dtype == SGG_F32) hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, R * S, C, K, Cpad, Kpad, (float*)wf, (float*)wd);
+    else return SGG_EINVAL;
+    return sgg_check_launch();
+}
+
+int sgg_conv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act, float leak, void* stream) {
+    if (!desc_ok(d) || !x || !w || !y) return SGG_EINVAL;
+    ConvArgs a = make_args(d, x, w, bias, y, act, leak);
+    return d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_FWD>(a, (hipStream_t)stream) : launch_gemm<float, MODE_FWD>(a, (hipStream_t)stream);
+}
+
+int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w, void* dx, void* stream) {
+    if (!desc_ok(d) || !dy || !w || !dx) return SGG_EINVAL;
+    ConvArgs a = make_args(d, dy, w, nullptr, dx, SGG_ACT_NONE, 0.f);
+    return d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_DGRAD>(a, (hipStream_t)stream) : launch_gemm<float, MODE_DGRAD>(a, (hipStream_t)stream);
+}
+
+size_t sgg_conv2d_bwd_weight_workspace(const sgg_conv_desc* d) {
+    if (!desc_ok(d)) return 0;
+    return (size_t)wgrad_splits(d) * d->R * d->S * d->C * d->K * sizeof(float);
+}
+
+int sgg_conv2d_bwd_weight(const sgg_conv_desc* d, const void* x, const void* dy, float* dw, int Cr, int Kr, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    if (!desc_ok(d) || !x || !dy || !dw || Cr <= 0 || Kr <= 0 || Cr > d->C || Kr > d->K) return SGG_EINVAL;
+    return d->dtype == SGG_BF16 ? run_wgrad<bf16>(d, x, dy, dw, Cr, Kr, accumulate, ws, ws_bytes, (hipStream_t)stream)
+                                : run_wgrad<float>(d, x, dy, dw, Cr, Kr, accumulate, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int sgg_deconv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act, float leak, void* stream) {
+    if (!desc_ok(d) || d->pad_mode != SGG_PAD_ZERO || !x || !w || !y) return SGG_EINVAL;
+    ConvArgs a = make_args(d, x, w, bias, y, act, leak);
+    return d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_DGRAD>(a, (hipStream_t)stream) : launch_gemm<float, MODE_DGRAD>(a, (hipStream_t)stream);
+}
+
+int sgg_deconv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w, void* dx, void* stream) {
+    if (!desc_ok(d) || d->pad_mode != SGG_PAD_ZERO || !dy || !w || !dx) return SGG_EINVAL;
+    ConvArgs a = make_args(d, dy, w, nullptr, dx, SGG_ACT_NONE, 0.f);
+    return d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_FWD>(a, (hipStream_t)stream) : launch_gemm<float, MODE_FWD>(a, (hipStream_t)stream);
+}
+
+int sgg_deconv2d_bwd_weight(const sgg_conv_desc* d, const void* x, const void* dy, float* dw, int Cr, int Kr, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    // deconv input x plays the conv-output role, deconv output-gradient dy the conv-input role
+    return sgg_conv2d_bwd_weight(d, dy, x, dw, Cr, Kr, accumulate, ws, ws_bytes, stream);
+}
+
+}  // extern "C"

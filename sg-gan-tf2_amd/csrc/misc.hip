@@ -1,0 +1,378 @@
+// misc.hip -- the small HBM-bound kernels of the train step: activations, bias gradient, semantic mask
+// multiply-reduce (module.py:312-314), losses (model.py:149-166), Keras-form Adam (model.py:199-207), the
+// colour->class-index map (segment_class.py:60-99), one-hot + resample of the mask (utils.py:158-165,197-199)
+// and the channel pad/unpad at the boundary.
+#include "common.h"
+
+// ---------------------------------------------------------------- activations / add
+template <typename T, int OP>   // OP 0: act fwd (a=x)   1: act bwd (a=dy, b=y)   2: add (a+b)
+__global__ __launch_bounds__(256) void eltwise_kernel(const char* a, const char* b, char* o, int64_t nvec, int act, float leak) {
+    constexpr int VEC = ET<T>::VEC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        float av[VEC], bv[VEC], ov[VEC];
+        ET<T>::unpack(ld16(a + i * 16), av);
+        if (OP != 0) ET<T>::unpack(ld16(b + i * 16), bv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            if (OP == 0) ov[e] = act_apply(av[e], act, leak);
+            else if (OP == 1) {
+                float d = 1.f;
+                if (act == SGG_ACT_RELU) d = bv[e] > 0.f ? 1.f : 0.f;
+                else if (act == SGG_ACT_LRELU) d = bv[e] > 0.f ? 1.f : leak;
+                else if (act == SGG_ACT_TANH) d = 1.f - bv[e] * bv[e];
+                ov[e] = av[e] * d;
+            } else ov[e] = av[e] + bv[e];
+        }
+        st16(o + i * 16, ET<T>::pack(ov));
+    }
+}
+
+template <int OP>
+static int launch_eltwise(const void* a, const void* b, void* o, int64_t n, int act, float leak, int dtype, void* stream) {
+    if (!a || !o || n < 0 || (OP != 0 && !b)) return SGG_EINVAL;
+    if (n == 0) return SGG_OK;
+    int vec = dtype == SGG_BF16 ? 8 : 4;
+    if (n % vec) return SGG_EINVAL;
+    int64_t nvec = n / vec;
+    int blocks = (int)((nvec + 255) / 256); if (blocks > 4096) blocks = 4096;
+    if (dtype == SGG_BF16) hipLaunchKernelGGL((eltwise_kernel<bf16, OP>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char*)a, (const char*)b, (char*)o, nvec, act, leak);
+    else if (dtype == SGG_F32) hipLaunchKernelGGL((eltwise_kernel<float, OP>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char*)a, (const char*)b, (char*)o, nvec, act, leak);
+    else return SGG_EINVAL;
+    return sgg_check_launch();
+}
+
+// ---------------------------------------------------------------- column sums (bias gradient)
+#define BG_ROWS 1024
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const char* dy, float* partial, int64_t P, int C) {
+    constexpr int VEC = ET<T>::VEC;
+    const int CV = C / VEC;
+    const int64_t p0 = (int64_t)blockIdx.x * BG_ROWS, p1 = p0 + BG_ROWS < P ? p0 + BG_ROWS : P;
+    __shared__ float red[256][VEC + 1];
+    for (int cvb = 0; cvb < CV; cvb += 256) {
+        const int lanes = CV - cvb < 256 ? CV - cvb : 256, rows = 256 / lanes;
+        const int cv = cvb + (int)(threadIdx.x % lanes), prow = threadIdx.x / lanes;
+        float s[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+        if (prow < rows)
+            for (int64_t p = p0 + prow; p < p1; p += rows) {
+                float v[VEC];
+                ET<T>::unpack(ld16(dy + ((size_t)p * C + (size_t)cv * VEC) * sizeof(T)), v);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s[e] += v[e];
+            }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) red[threadIdx.x][e] = s[e];
+        __syncthreads();
+        for (int item = threadIdx.x; item < lanes * VEC; item += 256) {
+            int l = item / VEC, e = item % VEC;
+            float acc = 0.f;
+            for (int r = 0; r < rows; ++r) acc += red[r * lanes + l][e];
+            partial[(size_t)blockIdx.x * C + (cvb + l) * VEC + e] = acc;
+        }
+        __syncthreads();
+    }
+}
+__global__ void colsum_final_kernel(const float* partial, float* out, int C, int Cr, int chunks, int accumulate) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cr) return;
+    double s = 0.0;
+    for (int k = 0; k < chunks; ++k) s += (double)partial[(size_t)k * C + c];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+// ---------------------------------------------------------------- semantic mask multiply-reduce
+template <typename T>
+__global__ void mask_reduce_fwd_kernel(const T* h4, const float* mask, float* out, int N, int hh, int hw, int mh, int mw, int Cr, int Cp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int total = N * mh * mw;
+    if (i >= total) return;
+    int n = i / (mh * mw), rem = i % (mh * mw), y = rem / mw, x = rem % mw;
+    int hy = hh == 1 ? 0 : y, hx = hw == 1 ? 0 : x;
+    const T* h = h4 + (((size_t)n * hh + hy) * hw + hx) * Cp;
+    const float* m = mask + (size_t)i * Cr;
+    float s = 0.f;
+    for (int c = 0; c < Cr; ++c) s += (float)h[c] * m[c];
+    out[i] = s;
+}
+template <typename T>
+__global__ void mask_reduce_bwd_kernel(const float* dout, const float* mask, T* dh4, int N, int hh, int hw, int mh, int mw, int Cr, int Cp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int total = N * hh * hw * Cp;
+    if (i >= total) return;
+    int c = i % Cp, t = i / Cp, hx = t % hw, hy = (t / hw) % hh, n = t / (hw * hh);
+    float s = 0.f;
+    if (c < Cr) {
+        int y0 = hh == 1 ? 0 : hy, y1 = hh == 1 ? mh : hy + 1;
+        int x0 = hw == 1 ? 0 : hx, x1 = hw == 1 ? mw : hx + 1;
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                size_t cell = ((size_t)n * mh + y) * mw + x;
+                s += dout[cell] * mask[cell * Cr + c];
+            }
+    }
+    dh4[i] = (T)s;
+}
+
+// ---------------------------------------------------------------- losses (single block: the maps are tiny / staged)
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* x, int64_t n, float label, float weight, float gscale,
+                                                         float* loss, float* dx, int accumulate) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        float v = x[i];
+        s += (double)(fmaxf(v, 0.f) - v * label + log1pf(expf(-fabsf(v))));
+        float sig = 1.f / (1.f + expf(-v));
+        float g = weight * gscale * (sig - label) / (float)n;
+        if (dx) dx[i] = (accumulate & 2) ? dx[i] + g : g;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0 && loss) { float l = (float)(weight * red[0] / (double)n); *loss = (accumulate & 1) ? *loss + l : l; }
+}
+
+#define L1_ROWS 2048
+template <typename T>
+__global__ __launch_bounds__(256) void l1_partial_kernel(const char* a, const char* b, char* db, float* partial, int64_t nvec,
+                                                         int Cr, int Cp, float gval) {
+    constexpr int VEC = ET<T>::VEC;
+    const int64_t i0 = (int64_t)blockIdx.x * L1_ROWS;
+    const int64_t i1 = i0 + L1_ROWS < nvec ? i0 + L1_ROWS : nvec;
+    float s = 0.f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        float av[VEC], bv[VEC], g[VEC];
+        ET<T>::unpack(ld16(a + i * 16), av);
+        ET<T>::unpack(ld16(b + i * 16), bv);
+        int c0 = (int)((i * VEC) % Cp);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float d = av[e] - bv[e];
+            bool real = (c0 + e) < Cr;
+            s += real ? fabsf(d) : 0.f;
+            g[e] = real ? (d > 0.f ? -gval : (d < 0.f ? gval : 0.f)) : 0.f;      // d/db |a-b| = -sign(a-b)
+        }
+        if (db) st16(db + i * 16, ET<T>::pack(g));
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void l1_final_kernel(const float* partial, int chunks, double scale, float* loss, int accumulate) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < chunks; i += 256) s += (double)partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) { float l = (float)(red[0] * scale); *loss = accumulate ? *loss + l : l; }
+}
+
+// ---------------------------------------------------------------- Adam (Keras form), flat buffer
+__global__ __launch_bounds__(256) void adam_kernel(float* th, const float* g, float* m, float* v, int64_t n, float lr_t,
+                                                   float b1, float b2, float eps, float gs) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i] * gs;
+        float mi = b1 * m[i] + (1.f - b1) * gi;
+        float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        th[i] = th[i] - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// ---------------------------------------------------------------- colour -> class index (integer, bit exact)
+// segment_class.py:63-66: 21 colours -> {1..7}; default 0.  Keys are 24-bit (R<<16|G<<8|B).
+#define SGG_SEG_KEYS 0x804080, 0xF423E8, 0xFAAAA0, 0xE6968C, 0x464646, 0x66669C, 0xBE9999, 0xB4A5B4, 0x966464, 0x96785A, \
+                     0x6B8E23, 0x4682B4, 0xDC143C, 0xFF0000, 0x00008E, 0x000046, 0x003C64, 0x00005A, 0x00006E, 0x0000E6, 0x770B20
+#define SGG_SEG_VALS 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 7, 6, 2, 2, 1, 1, 1, 1, 1, 3, 3
+__constant__ uint32_t kSegKeys[21] = {SGG_SEG_KEYS};
+__constant__ uint8_t kSegVals[21] = {SGG_SEG_VALS};
+static const uint32_t hSegKeys[21] = {SGG_SEG_KEYS};     // host copy, exported for the CPU-side table check
+static const uint8_t hSegVals[21] = {SGG_SEG_VALS};
+
+__global__ __launch_bounds__(256) void seg_class_kernel(const uint8_t* rgb, int ch, int64_t n, uint8_t* out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint8_t* p = rgb + i * ch;
+        uint32_t key = ((uint32_t)p[0] << 16) | ((uint32_t)p[1] << 8) | p[2];
+        uint8_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 21; ++k) v = key == kSegKeys[k] ? kSegVals[k] : v;
+        out[i] = v;
+    }
+}
+
+__global__ void onehot_resample_kernel(const uint8_t* idx, float* mask, int N, int H, int W, int oh, int ow, int nc) {
+    int64_t total = (int64_t)N * oh * ow * nc;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % nc);
+        int64_t t = i / nc;
+        int x = (int)(t % ow), y = (int)((t / ow) % oh), n = (int)(t / ((int64_t)ow * oh));
+        // align-corners nearest, round half up; exact rational arithmetic: floor((2*y*(H-1) + (oh-1)) / (2*(oh-1)))
+        int sy = oh == 1 ? 0 : (int)((2ll * y * (H - 1) + (oh - 1)) / (2ll * (oh - 1)));
+        int sx = ow == 1 ? 0 : (int)((2ll * x * (W - 1) + (ow - 1)) / (2ll * (ow - 1)));
+        mask[i] = idx[((size_t)n * H + sy) * W + sx] == c ? 1.f : 0.f;
+    }
+}
+
+template <typename T>
+__global__ void pad_channels_kernel(const float* src, T* dst, int64_t P, int Cs, int Cd) {
+    int64_t total = P * Cd;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % Cd);
+        int64_t p = i / Cd;
+        dst[i] = (T)(c < Cs ? src[p * Cs + c] : 0.f);
+    }
+}
+template <typename T>
+__global__ void unpad_channels_kernel(const T* src, float* dst, int64_t P, int Cs, int Cd) {
+    int64_t total = P * Cd;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % Cd);
+        int64_t p = i / Cd;
+        dst[i] = (float)src[p * Cs + c];
+    }
+}
+
+static inline int grid_for(int64_t n, int cap = 4096) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+extern "C" {
+
+int sgg_version(void) { return SGG_VERSION; }
+
+const char* sgg_strerror(int status) {
+    switch (status) {
+        case SGG_OK: return "SGG_OK";
+        case SGG_EINVAL: return "SGG_EINVAL: invalid argument";
+        case SGG_EUNSUPPORTED: return "SGG_EUNSUPPORTED: unsupported configuration";
+        case SGG_ELAUNCH: return "SGG_ELAUNCH: kernel launch failed";
+        case SGG_EWORKSPACE: return "SGG_EWORKSPACE: workspace missing or too small";
+        default: return "SGG_E?: unknown status";
+    }
+}
+
+int sgg_act_fwd(const void* x, void* y, int64_t n, int act, float leak, int dtype, void* stream) {
+    return launch_eltwise<0>(x, nullptr, y, n, act, leak, dtype, stream);
+}
+int sgg_act_bwd(const void* dy, const void* y, void* dx, int64_t n, int act, float leak, int dtype, void* stream) {
+    return launch_eltwise<1>(dy, y, dx, n, act, leak, dtype, stream);
+}
+int sgg_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream) {
+    return launch_eltwise<2>(a, b, out, n, 0, 0.f, dtype, stream);
+}
+
+size_t sgg_bias_grad_workspace(int64_t P, int C) {
+    if (P <= 0 || C <= 0) return 0;
+    return (size_t)((P + BG_ROWS - 1) / BG_ROWS) * C * sizeof(float);
+}
+int sgg_bias_grad(const void* dy, float* db, int64_t P, int C, int C_real, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !db || P <= 0 || C <= 0 || C % SGG_CPAD || C_real <= 0 || C_real > C) return SGG_EINVAL;
+    if (!ws || ws_bytes < sgg_bias_grad_workspace(P, C)) return SGG_EWORKSPACE;
+    int chunks = (int)((P + BG_ROWS - 1) / BG_ROWS);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SGG_BF16) hipLaunchKernelGGL(colsum_partial_kernel<bf16>, dim3(chunks), dim3(256), 0, s, (const char*)dy, (float*)ws, P, C);
+    else if (dtype == SGG_F32) hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(chunks), dim3(256), 0, s, (const char*)dy, (float*)ws, P, C);
+    else return SGG_EINVAL;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, db, C, C_real, chunks, accumulate);
+    return sgg_check_launch();
+}
+
+static bool mask_dims_ok(int N, int hh, int hw, int mh, int mw, int Cr, int Cp) {
+    if (N <= 0 || hh <= 0 || hw <= 0 || mh <= 0 || mw <= 0 || Cr <= 0 || Cp < Cr || Cp % SGG_CPAD) return false;
+    if (!((hh == mh || hh == 1) && (hw == mw || hw == 1))) return false;   // Keras multiply broadcast rule
+    return true;
+}
+int sgg_mask_reduce_fwd(const void* h4, const float* mask, float* out, int N, int hh, int hw, int mh, int mw, int Cr, int Cp, int dtype, void* stream) {
+    if (!h4 || !mask || !out || !mask_dims_ok(N, hh, hw, mh, mw, Cr, Cp)) return SGG_EINVAL;
+    int total = N * mh * mw;
+    if (dtype == SGG_BF16) hipLaunchKernelGGL(mask_reduce_fwd_kernel<bf16>, dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const bf16*)h4, mask, out, N, hh, hw, mh, mw, Cr, Cp);
+    else if (dtype == SGG_F32) hipLaunchKernelGGL(mask_reduce_fwd_kernel<float>, dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const float*)h4, mask, out, N, hh, hw, mh, mw, Cr, Cp);
+    else return SGG_EINVAL;
+    return sgg_check_launch();
+}
+int sgg_mask_reduce_bwd(const float* dout, const float* mask, void* dh4, int N, int hh, int hw, int mh, int mw, int Cr, int Cp, int dtype, void* stream) {
+    if (!dout || !mask || !dh4 || !mask_dims_ok(N, hh, hw, mh, mw, Cr, Cp)) return SGG_EINVAL;
+    int total = N * hh * hw * Cp;
+    if (dtype == SGG_BF16) hipLaunchKernelGGL(mask_reduce_bwd_kernel<bf16>, dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream, dout, mask, (bf16*)dh4, N, hh, hw, mh, mw, Cr, Cp);
+    else if (dtype == SGG_F32) hipLaunchKernelGGL(mask_reduce_bwd_kernel<float>, dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream, dout, mask, (float*)dh4, N, hh, hw, mh, mw, Cr, Cp);
+    else return SGG_EINVAL;
+    return sgg_check_launch();
+}
+
+int sgg_bce_logits(const float* logits, int64_t n, float label, float weight, float gscale, float* loss, float* dlogits, int accumulate, void* stream) {
+    if (!logits || n <= 0) return SGG_EINVAL;
+    hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, n, label, weight, gscale, loss, dlogits, accumulate);
+    return sgg_check_launch();
+}
+
+size_t sgg_l1_loss_workspace(int64_t P, int Cpad) {
+    if (P <= 0 || Cpad <= 0) return 0;
+    int64_t nvec = P * Cpad / 4;      // worst case (f32)
+    return (size_t)((nvec + L1_ROWS - 1) / L1_ROWS) * sizeof(float);
+}
+int sgg_l1_loss(const void* a, const void* b, int64_t P, int Cr, int Cp, float weight, float gscale, float* loss, void* db,
+                int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (!a || !b || !loss || P <= 0 || Cr <= 0 || Cp < Cr || Cp % SGG_CPAD) return SGG_EINVAL;
+    if (!ws || ws_bytes < sgg_l1_loss_workspace(P, Cp)) return SGG_EWORKSPACE;
+    int vec = dtype == SGG_BF16 ? 8 : 4;
+    int64_t nvec = P * Cp / vec;
+    int chunks = (int)((nvec + L1_ROWS - 1) / L1_ROWS);
+    double cnt = (double)P * Cr;
+    float gval = (float)((double)weight * gscale / cnt);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SGG_BF16) hipLaunchKernelGGL(l1_partial_kernel<bf16>, dim3(chunks), dim3(256), 0, s, (const char*)a, (const char*)b, (char*)db, (float*)ws, nvec, Cr, Cp, gval);
+    else if (dtype == SGG_F32) hipLaunchKernelGGL(l1_partial_kernel<float>, dim3(chunks), dim3(256), 0, s, (const char*)a, (const char*)b, (char*)db, (float*)ws, nvec, Cr, Cp, gval);
+    else return SGG_EINVAL;
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, chunks, (double)weight / cnt, loss, accumulate);
+    return sgg_check_launch();
+}
+
+int sgg_adam(float* theta, const float* g, float* m, float* v, int64_t n, int t, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    if (!theta || !g || !m || !v || n < 0 || t < 1) return SGG_EINVAL;
+    if (n == 0) return SGG_OK;
+    double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, n, (float)lr_t, beta1, beta2, eps, grad_scale);
+    return sgg_check_launch();
+}
+
+int sgg_seg_class_table(uint32_t* keys_host, uint8_t* vals_host, int capacity) {
+    if (!keys_host || !vals_host || capacity < 21) return SGG_EINVAL;
+    for (int i = 0; i < 21; ++i) { keys_host[i] = hSegKeys[i]; vals_host[i] = hSegVals[i]; }
+    return 21;
+}
+
+int sgg_seg_class_map(const uint8_t* rgb, int channels, int64_t n_pixels, uint8_t* out, void* stream) {
+    if (!rgb || !out || channels < 3 || n_pixels < 0) return SGG_EINVAL;
+    if (n_pixels == 0) return SGG_OK;
+    hipLaunchKernelGGL(seg_class_kernel, dim3(grid_for(n_pixels, 2048)), dim3(256), 0, (hipStream_t)stream, rgb, channels, n_pixels, out);
+    return sgg_check_launch();
+}
+
+int sgg_onehot_resample(const uint8_t* idx, float* mask, int N, int H, int W, int oh, int ow, int n_classes, void* stream) {
+    if (!idx || !mask || N <= 0 || H <= 0 || W <= 0 || oh <= 0 || ow <= 0 || n_classes <= 0) return SGG_EINVAL;
+    int64_t total = (int64_t)N * oh * ow * n_classes;
+    hipLaunchKernelGGL(onehot_resample_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, idx, mask, N, H, W, oh, ow, n_classes);
+    return sgg_check_launch();
+}
+
+int sgg_pad_channels(const float* src, void* dst, int64_t P, int Cs, int Cd, int dtype, void* stream) {
+    if (!src || !dst || P <= 0 || Cs <= 0 || Cd < Cs) return SGG_EINVAL;
+    if (dtype == SGG_BF16) hipLaunchKernelGGL(pad_channels_kernel<bf16>, dim3(grid_for(P * Cd)), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, P, Cs, Cd);
+    else if (dtype == SGG_F32) hipLaunchKernelGGL(pad_channels_kernel<float>, dim3(grid_for(P * Cd)), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, P, Cs, Cd);
+    else return SGG_EINVAL;
+    return sgg_check_launch();
+}
+int sgg_unpad_channels(const void* src, float* dst, int64_t P, int Cs, int Cd, int dtype, void* stream) {
+    if (!src || !dst || P <= 0 || Cd <= 0 || Cs < Cd) return SGG_EINVAL;
+    if (dtype == SGG_BF16) hipLaunchKernelGGL(unpad_channels_kernel<bf16>, dim3(grid_for(P * Cd)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, dst, P, Cs, Cd);
+    else if (dtype == SGG_F32) hipLaunchKernelGGL(unpad_channels_kernel<float>, dim3(grid_for(P * Cd)), dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, P, Cs, Cd);
+    else return SGG_EINVAL;
+    return sgg_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,227 @@
+// norm.hip -- instance normalisation (tfa.layers.InstanceNormalization, module.py:212..308; ops.py:13-22 by name)
+// fused with the following activation (module.py:213,234,...; LeakyReLU :289-309) and the residual add (:217).
+//
+// HBM-bound.  NHWC: a thread owns one 16-byte channel vector and walks pixels, so every access is a coalesced
+// 16-byte load and the per-(n,c) reduction never crosses channels.  Two passes per direction:
+//   fwd : partial (sum, sumsq) per pixel-chunk -> finalize (mean, rstd; f64 combine, fixed order) -> apply
+//   bwd : partial (sum g, sum g*xhat)          -> finalize (+ dgamma, dbeta over n)               -> apply
+// Algorithmic bytes: fwd 2 reads + 1 write of the tensor, bwd 4 reads + 1 write.
+#include "common.h"
+
+#define IN_ROWS_PER_CHUNK 256        // pixels per partial-sum chunk
+
+// ws layout: partial[N][chunks][C][2] f32, then sums[N][C][2] f32 (bwd only)
+static inline int in_chunks(int64_t HW) { return (int)((HW + IN_ROWS_PER_CHUNK - 1) / IN_ROWS_PER_CHUNK); }
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void in_partial_kernel(const char* x, const char* dy, const float* gamma, const float* beta,
+                                                         const float* stats, float* partial, int64_t HW, int C, int chunks,
+                                                         int act, float leak) {
+    constexpr int VEC = ET<T>::VEC;
+    const int CV = C / VEC;                       // channel vectors per pixel
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int64_t p0 = (int64_t)chunk * IN_ROWS_PER_CHUNK;
+    const int64_t p1 = p0 + IN_ROWS_PER_CHUNK < HW ? p0 + IN_ROWS_PER_CHUNK : HW;
+    __shared__ float red[256][2 * VEC + 1];
+    // threads cover (pixel row, channel vector) pairs: cv = item % CV walks fastest
+    for (int cvb = 0; cvb < CV; cvb += 256) {
+        const int lanes = CV - cvb < 256 ? CV - cvb : 256;       // channel vectors handled in this sweep
+        const int rows = 256 / lanes;                            // pixel rows in flight
+        const int cv = cvb + (int)(threadIdx.x % lanes), prow = threadIdx.x / lanes;
+        float s1[VEC], s2[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s1[e] = s2[e] = 0.f;
+        float mu[VEC], rs[VEC], gm[VEC], bt[VEC];
+        if (BWD && prow < rows) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                int c = cv * VEC + e;
+                mu[e] = stats[((size_t)n * C + c) * 2]; rs[e] = stats[((size_t)n * C + c) * 2 + 1];
+                gm[e] = gamma[c]; bt[e] = beta[c];
+            }
+        }
+        if (prow < rows)
+            for (int64_t p = p0 + prow; p < p1; p += rows) {
+                size_t off = (((size_t)n * HW + p) * C + (size_t)cv * VEC) * sizeof(T);
+                float xv[VEC];
+                ET<T>::unpack(ld16(x + off), xv);
+                if (!BWD) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { s1[e] += xv[e]; s2[e] += xv[e] * xv[e]; }
+                } else {
+                    float gv[VEC];
+                    ET<T>::unpack(ld16(dy + off), gv);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        float xh = (xv[e] - mu[e]) * rs[e];
+                        float g = gv[e] * act_grad_from_pre(gm[e] * xh + bt[e], act, leak);
+                        s1[e] += g; s2[e] += g * xh;
+                    }
+                }
+            }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][VEC + e] = s2[e]; }
+        __syncthreads();
+        // fixed-order combine over the pixel rows of each channel vector
+        for (int item = threadIdx.x; item < lanes * VEC; item += 256) {
+            int l = item / VEC, e = item % VEC;
+            float a = 0.f, b = 0.f;
+            for (int r = 0; r < rows; ++r) { a += red[r * lanes + l][e]; b += red[r * lanes + l][VEC + e]; }
+            int c = (cvb + l) * VEC + e;
+            size_t o = (((size_t)n * chunks + chunk) * C + c) * 2;
+            partial[o] = a; partial[o + 1] = b;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void in_finalize_fwd_kernel(const float* partial, float* stats, int64_t HW, int C, int chunks, float eps, int NC) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NC) return;
+    int n = i / C, c = i % C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        size_t o = (((size_t)n * chunks + k) * C + c) * 2;
+        s1 += (double)partial[o]; s2 += (double)partial[o + 1];
+    }
+    double mean = s1 / (double)HW, var = s2 / (double)HW - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[(size_t)i * 2] = (float)mean;
+    stats[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// sums[n][c] = (sum g, sum g*xhat) / HW ;  dgamma[c] = sum_n sum g*xhat ; dbeta[c] = sum_n sum g
+__global__ void in_finalize_bwd_kernel(const float* partial, float* sums, float* dgamma, float* dbeta, int64_t HW, int C,
+                                       int chunks, int N, int Cr, int accumulate) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double tg = 0.0, tb = 0.0;
+    for (int n = 0; n < N; ++n) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < chunks; ++k) {
+            size_t o = (((size_t)n * chunks + k) * C + c) * 2;
+            s1 += (double)partial[o]; s2 += (double)partial[o + 1];
+        }
+        sums[((size_t)n * C + c) * 2] = (float)(s1 / (double)HW);
+        sums[((size_t)n * C + c) * 2 + 1] = (float)(s2 / (double)HW);
+        tb += s1; tg += s2;
+    }
+    if (c < Cr) {
+        dgamma[c] = accumulate ? dgamma[c] + (float)tg : (float)tg;
+        dbeta[c] = accumulate ? dbeta[c] + (float)tb : (float)tb;
+    }
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void in_apply_kernel(const char* x, const char* dy, const char* residual, const float* gamma,
+                                                       const float* beta, const float* stats, const float* sums, char* out,
+                                                       int64_t HW, int C, int rows_per_block, int act, float leak) {
+    constexpr int VEC = ET<T>::VEC;
+    const int CV = C / VEC;
+    const int n = blockIdx.y;
+    const int64_t p0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t p1 = p0 + rows_per_block < HW ? p0 + rows_per_block : HW;
+    for (int cvb = 0; cvb < CV; cvb += 256) {
+        const int lanes = CV - cvb < 256 ? CV - cvb : 256;
+        const int rows = 256 / lanes;
+        const int cv = cvb + (int)(threadIdx.x % lanes), prow = threadIdx.x / lanes;
+        if (prow >= rows) continue;
+        float A[VEC], B[VEC], mu[VEC], rs[VEC], gm[VEC], bt[VEC], m1[VEC], m2[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            int c = cv * VEC + e;
+            mu[e] = stats[((size_t)n * C + c) * 2]; rs[e] = stats[((size_t)n * C + c) * 2 + 1];
+            gm[e] = gamma[c]; bt[e] = beta[c];
+            A[e] = gm[e] * rs[e]; B[e] = bt[e] - mu[e] * A[e];
+            if (BWD) { m1[e] = sums[((size_t)n * C + c) * 2]; m2[e] = sums[((size_t)n * C + c) * 2 + 1]; }
+        }
+        for (int64_t p = p0 + prow; p < p1; p += rows) {
+            size_t off = (((size_t)n * HW + p) * C + (size_t)cv * VEC) * sizeof(T);
+            float xv[VEC], o[VEC];
+            ET<T>::unpack(ld16(x + off), xv);
+            if (!BWD) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] = act_apply(xv[e] * A[e] + B[e], act, leak);
+                if (residual) {
+                    float rv[VEC];
+                    ET<T>::unpack(ld16(residual + off), rv);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) o[e] += rv[e];
+                }
+            } else {
+                float gv[VEC];
+                ET<T>::unpack(ld16(dy + off), gv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float xh = (xv[e] - mu[e]) * rs[e];
+                    float g = gv[e] * act_grad_from_pre(gm[e] * xh + bt[e], act, leak);
+                    o[e] = A[e] * (g - m1[e] - xh * m2[e]);
+                }
+            }
+            st16(out + off, ET<T>::pack(o));
+        }
+    }
+}
+
+static int in_rows_per_block(int N, int64_t HW, int C, int vec) {
+    // aim for >= 2048 blocks of >= 64 pixels
+    int64_t r = HW * N / 2048;
+    if (r < 64) r = 64;
+    if (r > 4096) r = 4096;
+    return (int)r;
+}
+
+extern "C" {
+
+size_t sgg_instnorm_workspace(int N, int64_t HW, int C) {
+    if (N <= 0 || HW <= 0 || C <= 0) return 0;
+    return ((size_t)N * in_chunks(HW) * C * 2 + (size_t)N * C * 2) * sizeof(float);
+}
+
+int sgg_instnorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* stats,
+                     int N, int64_t HW, int C, float eps, int act, float leak, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !gamma || !beta || !y || !stats || N <= 0 || HW <= 0 || C <= 0 || C % SGG_CPAD) return SGG_EINVAL;
+    if (act == SGG_ACT_TANH) return SGG_EUNSUPPORTED;
+    if (!ws || ws_bytes < sgg_instnorm_workspace(N, HW, C)) return SGG_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    int chunks = in_chunks(HW);
+    float* partial = (float*)ws;
+    int rpb = in_rows_per_block(N, HW, C, 0);
+    dim3 gp(chunks, N), ga((unsigned)((HW + rpb - 1) / rpb), N);
+    if (dtype == SGG_BF16) {
+        hipLaunchKernelGGL((in_partial_kernel<bf16, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, act, leak);
+        hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, partial, stats, HW, C, chunks, eps, N * C);
+        hipLaunchKernelGGL((in_apply_kernel<bf16, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak);
+    } else if (dtype == SGG_F32) {
+        hipLaunchKernelGGL((in_partial_kernel<float, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, act, leak);
+        hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, partial, stats, HW, C, chunks, eps, N * C);
+        hipLaunchKernelGGL((in_apply_kernel<float, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak);
+    } else return SGG_EINVAL;
+    return sgg_check_launch();
+}
+
+int sgg_instnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
+                     float* dgamma, float* dbeta, int N, int64_t HW, int C, int C_real, int accumulate, int act, float leak,
+                     int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !gamma || !beta || !stats || !dx || !dgamma || !dbeta || N <= 0 || HW <= 0 || C <= 0 || C % SGG_CPAD || C_real <= 0 || C_real > C) return SGG_EINVAL;
+    if (act == SGG_ACT_TANH) return SGG_EUNSUPPORTED;
+    if (!ws || ws_bytes < sgg_instnorm_workspace(N, HW, C)) return SGG_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    int chunks = in_chunks(HW);
+    float* partial = (float*)ws;
+    float* sums = partial + (size_t)N * chunks * C * 2;
+    int rpb = in_rows_per_block(N, HW, C, 0);
+    dim3 gp(chunks, N), ga((unsigned)((HW + rpb - 1) / rpb), N);
+    if (dtype == SGG_BF16) {
+        hipLaunchKernelGGL((in_partial_kernel<bf16, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, act, leak);
+        hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, sums, dgamma, dbeta, HW, C, chunks, N, C_real, accumulate);
+        hipLaunchKernelGGL((in_apply_kernel<bf16, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak);
+    } else if (dtype == SGG_F32) {
+        hipLaunchKernelGGL((in_partial_kernel<float, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, act, leak);
+        hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, sums, dgamma, dbeta, HW, C, chunks, N, C_real, accumulate);
+        hipLaunchKernelGGL((in_apply_kernel<float, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak);
+    } else return SGG_EINVAL;
+    return sgg_check_launch();
+}
+
+}  // extern "C"

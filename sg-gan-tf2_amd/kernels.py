@@ -1,0 +1,276 @@
+"""Tensor-level launchers over the C ABI (one function per entry point of include/sggan.h).
+
+torch is used for device memory and streams only: every function passes raw device
+pointers + the current HIP stream to libsggan.so.  Tensors are NHWC, channel-padded
+to a multiple of 8 (see include/sggan.h), float32 (parity path) or bfloat16 (perf path).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import functools
+
+import torch
+
+from . import _abi as A
+
+_DT = {torch.float32: A.SGG_F32, torch.bfloat16: A.SGG_BF16}
+
+
+def dt(t_or_dtype) -> int:
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    try:
+        return _DT[d]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {d}: activations must be float32 or bfloat16")
+
+
+def cpad(c: int) -> int:
+    return (c + A.CPAD - 1) // A.CPAD * A.CPAD
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return C.c_void_p(t.data_ptr())
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_WS = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Per-device scratch buffer shared by all launches (single stream => in-order reuse is safe)."""
+    key = torch.device(device).index or 0
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def same_pads(n_in: int, k: int, s: int):
+    """TF 'SAME' (leading pad, trailing pad, output size): the extra pad goes bottom/right."""
+    out = -(-n_in // s)
+    total = max((out - 1) * s + k - n_in, 0)
+    return total // 2, total - total // 2, out
+
+
+class ConvGeom:
+    """Geometry of one Conv2D / Conv2DTranspose call site, resolved to an sgg_conv_desc."""
+    __slots__ = ("desc", "x_shape", "y_shape", "ws_wgrad", "dtype", "is_deconv")
+
+    def __init__(self, desc, x_shape, y_shape, dtype, is_deconv):
+        self.desc, self.x_shape, self.y_shape, self.dtype, self.is_deconv = desc, x_shape, y_shape, dtype, is_deconv
+        self.ws_wgrad = int(A.lib().sgg_conv2d_bwd_weight_workspace(C.byref(desc)))
+        if self.ws_wgrad == 0:
+            raise A.SggError(f"invalid convolution geometry {[(f, getattr(desc, f)) for f, _ in desc._fields_]}")
+
+
+@functools.lru_cache(maxsize=None)
+def conv_geom(N, H, W, C_, K, R, S, stride, padding, reflect, dtype) -> ConvGeom:
+    """tf.keras.layers.Conv2D geometry: padding 'SAME'|'VALID', or reflect=p (tf.pad REFLECT then VALID)."""
+    if reflect:
+        assert padding == "VALID" and stride == 1
+        pt = pl = reflect
+        Ho, Wo = H + 2 * reflect - R + 1, W + 2 * reflect - S + 1
+        mode = A.PAD_REFLECT
+    elif padding == "SAME":
+        pt, _, Ho = same_pads(H, R, stride)
+        pl, _, Wo = same_pads(W, S, stride)
+        mode = A.PAD_ZERO
+    elif padding == "VALID":
+        pt = pl = 0
+        Ho, Wo = (H - R) // stride + 1, (W - S) // stride + 1
+        mode = A.PAD_ZERO
+    else:
+        raise ValueError(padding)
+    if Ho <= 0 or Wo <= 0:
+        raise ValueError(f"convolution output is empty for input {H}x{W}, kernel {R}x{S}, stride {stride}, {padding}")
+    d = A.ConvDesc(N, H, W, C_, K, R, S, stride, pt, pl, Ho, Wo, mode, dt(dtype))
+    return ConvGeom(d, (N, H, W, C_), (N, Ho, Wo, K), dtype, False)
+
+
+@functools.lru_cache(maxsize=None)
+def deconv_geom(N, Hin, Win, Cin, Cout, R, S, stride, dtype) -> ConvGeom:
+    """Conv2DTranspose(padding='same'): described by the equivalent conv whose INPUT is the deconv OUTPUT."""
+    H, W = Hin * stride, Win * stride
+    pt, _, oh = same_pads(H, R, stride)
+    pl, _, ow = same_pads(W, S, stride)
+    assert oh == Hin and ow == Win
+    d = A.ConvDesc(N, H, W, Cout, Cin, R, S, stride, pt, pl, Hin, Win, A.PAD_ZERO, dt(dtype))
+    return ConvGeom(d, (N, Hin, Win, Cin), (N, H, W, Cout), dtype, True)
+
+
+# ----------------------------------------------------------------------------- weights
+def pack_weights(w_hwio: torch.Tensor, Cp: int, Kp: int, dtype, want_fwd=True, want_dgrad=True):
+    R, S, Cr, Kr = w_hwio.shape
+    assert w_hwio.dtype == torch.float32
+    wf = torch.empty((Kp, R * S * Cp), dtype=dtype, device=w_hwio.device) if want_fwd else None
+    wd = torch.empty((Cp, R * S * Kp), dtype=dtype, device=w_hwio.device) if want_dgrad else None
+    A.check(A.lib().sgg_pack_conv_weights(_p(w_hwio), R, S, Cr, Kr, Cp, Kp, dt(dtype), _p(wf), _p(wd), _s()), "pack_conv_weights")
+    return wf, wd
+
+
+# ----------------------------------------------------------------------------- conv / deconv
+def conv_fwd(g: ConvGeom, x, w_fwd, bias, act=A.ACT_NONE, leak=0.0):
+    assert tuple(x.shape) == g.x_shape and not g.is_deconv, (tuple(x.shape), g.x_shape)
+    y = torch.empty(g.y_shape, dtype=x.dtype, device=x.device)
+    A.check(A.lib().sgg_conv2d_fwd(C.byref(g.desc), _p(x), _p(w_fwd), _p(bias), _p(y), act, leak, _s()), "conv2d_fwd")
+    return y
+
+
+def conv_dgrad(g: ConvGeom, dy, w_dgrad):
+    assert tuple(dy.shape) == g.y_shape and not g.is_deconv
+    dx = torch.empty(g.x_shape, dtype=dy.dtype, device=dy.device)
+    A.check(A.lib().sgg_conv2d_bwd_data(C.byref(g.desc), _p(dy), _p(w_dgrad), _p(dx), _s()), "conv2d_bwd_data")
+    return dx
+
+
+def conv_wgrad(g: ConvGeom, x, dy, dw, accumulate=False):
+    """dw: f32 (R,S,C_real,K_real) view to write / accumulate into."""
+    assert tuple(x.shape) == g.x_shape and tuple(dy.shape) == g.y_shape and dw.dtype == torch.float32
+    ws = workspace(g.ws_wgrad, x.device)
+    A.check(A.lib().sgg_conv2d_bwd_weight(C.byref(g.desc), _p(x), _p(dy), _p(dw), dw.shape[2], dw.shape[3], int(accumulate),
+                                          _p(ws), ws.numel(), _s()), "conv2d_bwd_weight")
+
+
+def deconv_fwd(g: ConvGeom, x, w_dgrad, bias, act=A.ACT_NONE, leak=0.0):
+    assert tuple(x.shape) == g.x_shape and g.is_deconv
+    y = torch.empty(g.y_shape, dtype=x.dtype, device=x.device)
+    A.check(A.lib().sgg_deconv2d_fwd(C.byref(g.desc), _p(x), _p(w_dgrad), _p(bias), _p(y), act, leak, _s()), "deconv2d_fwd")
+    return y
+
+
+def deconv_dgrad(g: ConvGeom, dy, w_fwd):
+    assert tuple(dy.shape) == g.y_shape and g.is_deconv
+    dx = torch.empty(g.x_shape, dtype=dy.dtype, device=dy.device)
+    A.check(A.lib().sgg_deconv2d_bwd_data(C.byref(g.desc), _p(dy), _p(w_fwd), _p(dx), _s()), "deconv2d_bwd_data")
+    return dx
+
+
+def deconv_wgrad(g: ConvGeom, x, dy, dw, accumulate=False):
+    """dw: f32 (R,S,Cout_real,Cin_real) -- the Keras transpose-kernel layout."""
+    assert tuple(x.shape) == g.x_shape and tuple(dy.shape) == g.y_shape
+    ws = workspace(g.ws_wgrad, x.device)
+    A.check(A.lib().sgg_deconv2d_bwd_weight(C.byref(g.desc), _p(x), _p(dy), _p(dw), dw.shape[2], dw.shape[3], int(accumulate),
+                                            _p(ws), ws.numel(), _s()), "deconv2d_bwd_weight")
+
+
+def bias_grad(dy, db, accumulate=False):
+    """db[c] (+)= sum over all pixels of dy[..., c] for c < db.numel()."""
+    Cp = dy.shape[-1]
+    P = dy.numel() // Cp
+    need = int(A.lib().sgg_bias_grad_workspace(P, Cp))
+    ws = workspace(need, dy.device)
+    A.check(A.lib().sgg_bias_grad(_p(dy), _p(db), P, Cp, db.numel(), int(accumulate), dt(dy), _p(ws), ws.numel(), _s()), "bias_grad")
+
+
+# ----------------------------------------------------------------------------- instance norm / activations
+def instnorm_fwd(x, gamma, beta, residual=None, eps=1e-3, act=A.ACT_NONE, leak=0.0):
+    N, H, W, Cp = x.shape
+    assert gamma.numel() == Cp and beta.numel() == Cp, "gamma/beta must be channel-padded"
+    y = torch.empty_like(x)
+    stats = torch.empty((N, Cp, 2), dtype=torch.float32, device=x.device)
+    ws = workspace(int(A.lib().sgg_instnorm_workspace(N, H * W, Cp)), x.device)
+    A.check(A.lib().sgg_instnorm_fwd(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(stats), N, H * W, Cp, eps, act, leak,
+                                     dt(x), _p(ws), ws.numel(), _s()), "instnorm_fwd")
+    return y, stats
+
+
+def instnorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, accumulate=False, act=A.ACT_NONE, leak=0.0):
+    N, H, W, Cp = x.shape
+    dx = torch.empty_like(x)
+    ws = workspace(int(A.lib().sgg_instnorm_workspace(N, H * W, Cp)), x.device)
+    A.check(A.lib().sgg_instnorm_bwd(_p(dy), _p(x), _p(gamma), _p(beta), _p(stats), _p(dx), _p(dgamma), _p(dbeta), N, H * W, Cp,
+                                     dgamma.numel(), int(accumulate), act, leak, dt(x), _p(ws), ws.numel(), _s()), "instnorm_bwd")
+    return dx
+
+
+def act_fwd(x, act, leak=0.0):
+    y = torch.empty_like(x)
+    A.check(A.lib().sgg_act_fwd(_p(x), _p(y), x.numel(), act, leak, dt(x), _s()), "act_fwd")
+    return y
+
+
+def act_bwd(dy, y, act, leak=0.0):
+    dx = torch.empty_like(dy)
+    A.check(A.lib().sgg_act_bwd(_p(dy), _p(y), _p(dx), dy.numel(), act, leak, dt(dy), _s()), "act_bwd")
+    return dx
+
+
+def add(a, b):
+    o = torch.empty_like(a)
+    A.check(A.lib().sgg_add(_p(a), _p(b), _p(o), a.numel(), dt(a), _s()), "add")
+    return o
+
+
+# ----------------------------------------------------------------------------- mask / losses / optimizer
+def mask_reduce_fwd(h4, mask, C_real):
+    N, hh, hw, Cp = h4.shape
+    _, mh, mw, Cm = mask.shape
+    assert Cm == C_real and mask.dtype == torch.float32
+    out = torch.empty((N, mh, mw, 1), dtype=torch.float32, device=h4.device)
+    A.check(A.lib().sgg_mask_reduce_fwd(_p(h4), _p(mask), _p(out), N, hh, hw, mh, mw, C_real, Cp, dt(h4), _s()), "mask_reduce_fwd")
+    return out
+
+
+def mask_reduce_bwd(dout, mask, h4_shape, dtype, C_real):
+    N, hh, hw, Cp = h4_shape
+    _, mh, mw, _ = mask.shape
+    dh4 = torch.empty(h4_shape, dtype=dtype, device=dout.device)
+    A.check(A.lib().sgg_mask_reduce_bwd(_p(dout), _p(mask), _p(dh4), N, hh, hw, mh, mw, C_real, Cp, dt(dtype), _s()), "mask_reduce_bwd")
+    return dh4
+
+
+def bce_logits(logits, label, loss, dlogits=None, weight=1.0, gscale=1.0, accumulate_loss=False, accumulate_grad=False):
+    """loss: 1-element f32 tensor written/accumulated on device (no host sync)."""
+    assert logits.dtype == torch.float32
+    A.check(A.lib().sgg_bce_logits(_p(logits), logits.numel(), float(label), float(weight), float(gscale), _p(loss), _p(dlogits),
+                                   int(bool(accumulate_loss)) | (int(bool(accumulate_grad)) << 1), _s()), "bce_logits")
+
+
+def l1_loss(a, b, C_real, loss, db=None, weight=1.0, gscale=1.0, accumulate=False):
+    Cp = a.shape[-1]
+    P = a.numel() // Cp
+    ws = workspace(int(A.lib().sgg_l1_loss_workspace(P, Cp)), a.device)
+    A.check(A.lib().sgg_l1_loss(_p(a), _p(b), P, C_real, Cp, float(weight), float(gscale), _p(loss), _p(db), int(accumulate), dt(a),
+                                _p(ws), ws.numel(), _s()), "l1_loss")
+
+
+def adam(theta, g, m, v, t, lr=1e-3, beta1=0.5, beta2=0.999, eps=1e-7, grad_scale=1.0):
+    assert theta.dtype == torch.float32 and theta.numel() == g.numel() == m.numel() == v.numel()
+    A.check(A.lib().sgg_adam(_p(theta), _p(g), _p(m), _p(v), theta.numel(), int(t), lr, beta1, beta2, eps, grad_scale, _s()), "adam")
+
+
+# ----------------------------------------------------------------------------- data side
+def seg_class_map(rgb_u8):
+    """uint8 (..., M, N, 3|4) -> uint8 (..., M, N) class indices (segment_class.py:60-99), bit exact."""
+    assert rgb_u8.dtype == torch.uint8 and rgb_u8.shape[-1] >= 3
+    out = torch.empty(rgb_u8.shape[:-1], dtype=torch.uint8, device=rgb_u8.device)
+    A.check(A.lib().sgg_seg_class_map(_p(rgb_u8), rgb_u8.shape[-1], out.numel(), _p(out), _s()), "seg_class_map")
+    return out
+
+
+def onehot_resample(idx_u8, oh, ow, n_classes):
+    N, H, W = idx_u8.shape
+    mask = torch.empty((N, oh, ow, n_classes), dtype=torch.float32, device=idx_u8.device)
+    A.check(A.lib().sgg_onehot_resample(_p(idx_u8), _p(mask), N, H, W, oh, ow, n_classes, _s()), "onehot_resample")
+    return mask
+
+
+def pad_channels(x_f32, Cd, dtype):
+    Cs = x_f32.shape[-1]
+    out = torch.empty(x_f32.shape[:-1] + (Cd,), dtype=dtype, device=x_f32.device)
+    A.check(A.lib().sgg_pad_channels(_p(x_f32), _p(out), x_f32.numel() // Cs, Cs, Cd, dt(dtype), _s()), "pad_channels")
+    return out
+
+
+def unpad_channels(x, Cd):
+    Cs = x.shape[-1]
+    out = torch.empty(x.shape[:-1] + (Cd,), dtype=torch.float32, device=x.device)
+    A.check(A.lib().sgg_unpad_channels(_p(x), _p(out), x.numel() // Cs, Cs, Cd, dt(x), _s()), "unpad_channels")
+    return out

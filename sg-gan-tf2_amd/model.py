@@ -1,0 +1,182 @@
+"""``sggan`` -- host-side mirror of the reference's trainer object (model.py:39-566), hot path only.
+
+``train_step`` follows model.py:169-200 line by line (documented deviations: D2 -- ``fake_A =
+G(real_A)`` every step and ``da_fake`` evaluated once, since :187 and :188 are the same values).
+Everything numeric runs in libsggan.so; this file sequences kernels, owns the flat
+parameter/gradient buffers and (optionally) overlaps the data-parallel gradient all-reduce
+(RCCL over xGMI; one bucket per network) with the remaining backward work.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import _abi as A
+from . import kernels as K
+from .module import Discriminator, Generator
+
+_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32, "fp32": torch.float32,
+           "float32": torch.float32, torch.bfloat16: torch.bfloat16, torch.float32: torch.float32}
+
+
+def default_args(**over):
+    """The reference's argparse defaults (main.py:14-43) for the flags the step consumes, plus the
+    build's own knobs (dtype/device/n_blocks/seed), as a namespace."""
+    a = dict(batch_size=1, image_height=128, image_width=128, input_nc=3, output_nc=3, ngf=64, ndf=64,
+             segment_class=34, beta1=0.5, lr=0.0002, L1_lambda=10.0, Lg_lambda=5.0, use_resnet=True, use_pix2pix=False,
+             use_lsgan=True, ratio_gan2seg=10, max_size=50, phase="train", dataset_dir="city",
+             dtype="bf16", device="cuda", n_blocks=9, seed=19)
+    a.update(over)
+    return SimpleNamespace(**a)
+
+
+class sggan(object):
+    # model.py:151 ``LAMBDA = 100`` (hard-coded; --L1_lambda is ignored by the live step) and
+    # model.py:205 ``lr = 0.001`` (hard-coded; --lr is ignored) -- SURVEY.md 5 "Config / flags".
+    LAMBDA = 100.0
+    LR = 0.001
+
+    def __init__(self, args=None, **kw):
+        args = args if args is not None else default_args(**kw)
+        g = lambda k, d=None: getattr(args, k, d)
+        self.batch_size = g("batch_size", 1)
+        self.image_width, self.image_height = g("image_width", 128), g("image_height", 128)
+        self.input_c_dim, self.output_c_dim = g("input_nc", 3), g("output_nc", 3)
+        self.segment_class = g("segment_class", 34)
+        self.use_pix2pix = bool(g("use_pix2pix", False))
+        if self.use_pix2pix or not g("use_resnet", True):
+            raise NotImplementedError("only the ResNet generator / mask discriminator path is built "
+                                      "(generator_unet / *_pix2pix are out of scope, SURVEY.md 2.1)")
+        self.dtype = _DTYPES[g("dtype", "bf16")]
+        self.device = torch.device(g("device", "cuda"))
+        seed = g("seed", 19)
+        self.discriminator = Discriminator(df_dim=g("ndf", 64), in_c=self.output_c_dim, segment_class=self.segment_class,
+                                           dtype=self.dtype, device=self.device, seed=seed + 1)          # model.py:54
+        self.generator = Generator(gf_dim=g("ngf", 64), in_c=self.input_c_dim, out_c=self.output_c_dim,
+                                   n_blocks=g("n_blocks", 9), dtype=self.dtype, device=self.device, seed=seed)  # :56
+        self.beta1 = g("beta1", 0.5)
+        self.lr = self.LR
+        # step I/O attributes (model.py:250-256 sets the inputs; :260 reads the losses)
+        self.real_A = self.seg_A = self.mask_A = self.fake_A = None
+        self._loss = torch.zeros(2, dtype=torch.float32, device=self.device)    # [gen_loss, disc_loss] on device
+        self.gen_loss, self.disc_loss = self._loss[0:1], self._loss[1:2]
+        self._pg = None
+        self._world = 1
+
+    # ------------------------------------------------------------------ data parallel (new capability)
+    def enable_data_parallel(self, process_group=None):
+        """Average gradients over ranks with one all-reduce per network, launched as soon as that
+        network's backward has been queued so it overlaps with the rest of the step."""
+        import torch.distributed as dist
+        self._pg = process_group if process_group is not None else dist.group.WORLD
+        self._world = dist.get_world_size(self._pg)
+        for net in (self.generator, self.discriminator):       # identical replicas: broadcast rank 0's parameters
+            dist.broadcast(net.P.flat, src=dist.get_global_rank(self._pg, 0) if hasattr(dist, "get_global_rank") else 0, group=self._pg)
+            net.P.version += 1
+        return self
+
+    def _allreduce(self, net):
+        if self._pg is None:
+            return None
+        import torch.distributed as dist
+        return dist.all_reduce(net.P.grad, op=dist.ReduceOp.SUM, group=self._pg, async_op=True)
+
+    # ------------------------------------------------------------------ the hot path
+    def _prep(self, x):
+        t = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x, dtype=np.float32))
+        return self.generator.to_internal(t.to(self.device))
+
+    def train_step(self, args=None):
+        """model.py:169-200.  Reads ``real_A, seg_A`` (N,H,W,3) in [0,1] and ``mask_A`` (N,mh,mw,C);
+        writes ``fake_A, gen_loss, disc_loss``; updates G, D and both Adam states."""
+        G, D = self.generator, self.discriminator
+        real, seg = self._prep(self.real_A), self._prep(self.seg_A)
+        mask = self.mask_A if isinstance(self.mask_A, torch.Tensor) else torch.as_tensor(np.asarray(self.mask_A, dtype=np.float32))
+        mask = mask.to(device=self.device, dtype=torch.float32).contiguous()
+        G.P.zero_grad()
+        D.P.zero_grad()
+
+        fake, tG = G.forward(real)                                          # :175-179 (D2)
+        da_real, tDr = D.forward(seg, mask)                                 # :186
+        da_fake, tDf = D.forward(fake, mask)                                # :187 (= :188)
+
+        # losses + their logit gradients, all on device (no host sync)
+        gl, dl = self._loss[0:1], self._loss[1:2]
+        d_fake_g = torch.empty_like(da_fake)
+        d_real_d = torch.empty_like(da_real)
+        d_fake_d = torch.empty_like(da_fake)
+        dfake_l1 = torch.empty_like(fake)
+        K.bce_logits(da_fake, 1.0, gl, d_fake_g)                            # :153 gan_loss
+        K.l1_loss(seg, fake, self.output_c_dim, gl, dfake_l1, weight=self.LAMBDA, accumulate=True)   # :155-156
+        K.bce_logits(da_real, 1.0, dl, d_real_d)                            # :162
+        K.bce_logits(da_fake, 0.0, dl, d_fake_d, accumulate_loss=True)      # :163-164 (adds to disc_loss)
+
+        # disc_tape.gradient(disc_loss, D vars)  (:197)
+        D.backward(tDr, d_real_d, want_dx=False, param_grads=True)
+        D.backward(tDf, d_fake_d, want_dx=False, param_grads=True)
+        hD = self._allreduce(D)
+        # gen_tape.gradient(gen_loss, G vars)    (:196): through D's data path, then G
+        dfake = D.backward(tDf, d_fake_g, want_dx=True, param_grads=False)
+        dfake = K.add(dfake, dfake_l1)
+        G.backward(tG, dfake, want_dx=False, param_grads=True)
+        hG = self._allreduce(G)
+
+        scale = 1.0 / self._world
+        if hD is not None:
+            hD.wait()
+        D.P.adam_step(self.lr, self.beta1, grad_scale=scale)               # :200
+        if hG is not None:
+            hG.wait()
+        G.P.adam_step(self.lr, self.beta1, grad_scale=scale)               # :199
+        self._fake_internal = fake
+        self.fake_A = _LazyUnpad(fake, self.output_c_dim)
+        self.da_real, self.da_fake = da_real, da_fake
+        return self.gen_loss, self.disc_loss
+
+    # ------------------------------------------------------------------ convenience
+    def losses(self):
+        """Host copies of (gen_loss, disc_loss) -- the two scalars model.py:260 prints."""
+        v = self._loss.detach().cpu().tolist()
+        return v[0], v[1]
+
+    def state_dict(self):
+        G, D = self.generator.P, self.discriminator.P
+        return {"G": G.flat.cpu(), "D": D.flat.cpu(), "G_m": G.m.cpu(), "G_v": G.v.cpu(), "D_m": D.m.cpu(), "D_v": D.v.cpu(),
+                "G_t": G.step_count, "D_t": D.step_count}
+
+    def load_state_dict(self, sd):
+        for key, net in (("G", self.generator), ("D", self.discriminator)):
+            net.P.flat.copy_(sd[key]); net.P.m.copy_(sd[key + "_m"]); net.P.v.copy_(sd[key + "_v"])
+            net.P.step_count = int(sd[key + "_t"]); net.P.version += 1
+
+    def save(self, path):
+        """model.py:450-468 saves weights only; the optimizer slots are added here so training can resume."""
+        torch.save(self.state_dict(), path)
+
+    def load(self, path):
+        self.load_state_dict(torch.load(path, map_location="cpu"))
+        return True
+
+
+class _LazyUnpad:
+    """``self.fake_A``: the generator output kept in its internal layout; converts to the reference's
+    (N,H,W,3) float32 on demand so the step itself does no extra pass."""
+
+    def __init__(self, internal, c):
+        self._t, self._c = internal, c
+
+    def tensor(self):
+        return K.unpad_channels(self._t, self._c)
+
+    def numpy(self):
+        return self.tensor().cpu().numpy()
+
+    @property
+    def shape(self):
+        return tuple(self._t.shape[:-1]) + (self._c,)
+
+    def __array__(self, dtype=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)

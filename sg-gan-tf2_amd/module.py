@@ -1,0 +1,427 @@
+"""Network definitions of the SG-GAN hot path -- host-side mirror of the reference's ``module.py``.
+
+``generator_resnet()`` (module.py:219-269, with ``residule_block`` :208-217) and
+``discriminator()`` (module.py:272-318) keep the reference's names and call
+conventions (``generator(x)``, ``discriminator([x, mask])``) but run on an explicit
+forward/backward engine over the HIP kernels of libsggan.so: no tracing compiler, no
+autograd graph in the training loop.  Each network owns ONE flat f32 buffer for its
+parameters, one for gradients and two for the Adam slots, so the optimizer is a single
+launch and data-parallel training all-reduces one bucket per network.
+
+Deviation D3: ``gf_dim/df_dim/segment_class`` and the image size are
+parameters (defaults = the module-local constants of the reference); layers are
+shape-agnostic, geometry is resolved per call.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import _abi as A
+from . import kernels as K
+
+
+# ----------------------------------------------------------------------------- parameters
+class ParamStore:
+    """Flat parameter storage.  1-D parameters (bias, gamma, beta) are stored padded to the
+    channel granule (8) so kernels can index them by padded channel; padded entries stay 0."""
+
+    def __init__(self, specs, device):
+        self.specs = list(specs)
+        self.index = {}
+        off = 0
+        for name, shape in self.specs:
+            shape = tuple(int(s) for s in shape)
+            n = K.cpad(shape[0]) if len(shape) == 1 else int(np.prod(shape))
+            self.index[name] = (off, n, shape)
+            off += (n + 3) // 4 * 4
+        self.numel = off
+        self.device = torch.device(device)
+        z = lambda: torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+        self.flat, self.grad, self.m, self.v = z(), z(), z(), z()
+        self.version = 0            # bumped whenever parameter values change (re-pack trigger)
+        self.step_count = 0         # Adam t
+
+    # views ------------------------------------------------------------------
+    def _view(self, buf, name, padded):
+        off, n, shape = self.index[name]
+        if len(shape) == 1:
+            return buf[off:off + n] if padded else buf[off:off + shape[0]]
+        return buf[off:off + n].view(shape)
+
+    def p(self, name, padded=True):
+        return self._view(self.flat, name, padded)
+
+    def g(self, name, padded=False, buf=None):
+        return self._view(self.grad if buf is None else buf, name, padded)
+
+    def names(self):
+        return [n for n, _ in self.specs]
+
+    def n_real(self):
+        return sum(int(np.prod(s)) for _, s in self.specs)
+
+    # init / io ----------------------------------------------------------------
+    def init_keras(self, seed):
+        """Keras defaults: glorot_uniform kernels, zero bias, IN gamma=1 / beta=0."""
+        gen = torch.Generator(device="cpu").manual_seed(int(seed))
+        host = torch.zeros(self.numel, dtype=torch.float32)
+        for name, shape in self.specs:
+            off, n, shape = self.index[name]
+            if name.endswith("_w"):
+                rf = int(np.prod(shape[:-2]))
+                lim = math.sqrt(6.0 / (shape[-2] * rf + shape[-1] * rf))
+                host[off:off + n] = (torch.rand(n, generator=gen) * 2 - 1) * lim
+            elif name.endswith("_g"):
+                host[off:off + shape[0]] = 1.0
+        self.flat.copy_(host)
+        self.version += 1
+
+    def load(self, params: dict):
+        """name -> array in the reference layouts (HWIO kernels, (kh,kw,out,in) transpose kernels)."""
+        host = torch.zeros(self.numel, dtype=torch.float32)
+        for name, _ in self.specs:
+            off, n, shape = self.index[name]
+            a = torch.as_tensor(np.asarray(params[name], dtype=np.float32)).reshape(-1)
+            assert a.numel() == int(np.prod(shape)), (name, a.numel(), shape)
+            host[off:off + a.numel()] = a
+        self.flat.copy_(host)
+        self.version += 1
+
+    def export(self, buf=None) -> dict:
+        src = (self.flat if buf is None else buf).detach().cpu()
+        out = {}
+        for name, _ in self.specs:
+            off, n, shape = self.index[name]
+            out[name] = src[off:off + int(np.prod(shape))].view(shape).numpy().copy()
+        return out
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def adam_step(self, lr=1e-3, beta1=0.5, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        """tf.keras.optimizers.Adam.apply_gradients (model.py:199-200) over the whole network: one launch."""
+        self.step_count += 1
+        K.adam(self.flat, self.grad, self.m, self.v, self.step_count, lr, beta1, beta2, eps, grad_scale)
+        self.version += 1
+
+
+def generator_param_specs(gf_dim=64, in_c=3, out_c=3, n_blocks=9):
+    """(name, shape) in Keras ``trainable_variables`` creation order of generator_resnet (module.py:219-269)."""
+    L = []
+
+    def conv(name, shape, out_ch, norm=True):
+        L.append((name + "_w", shape))
+        L.append((name + "_b", (out_ch,)))
+        if norm:
+            L.append((name + "_g", (out_ch,)))
+            L.append((name + "_beta", (out_ch,)))
+
+    conv("c1", (7, 7, in_c, gf_dim), gf_dim)
+    conv("c2", (3, 3, gf_dim, gf_dim * 2), gf_dim * 2)
+    conv("c3", (3, 3, gf_dim * 2, gf_dim * 4), gf_dim * 4)
+    for i in range(1, n_blocks + 1):
+        conv(f"r{i}a", (3, 3, gf_dim * 4, gf_dim * 4), gf_dim * 4)
+        conv(f"r{i}b", (3, 3, gf_dim * 4, gf_dim * 4), gf_dim * 4)
+    conv("d1", (3, 3, gf_dim * 2, gf_dim * 4), gf_dim * 2)     # Conv2DTranspose kernel: (kh,kw,out,in)
+    conv("d2", (3, 3, gf_dim, gf_dim * 2), gf_dim)
+    conv("out", (7, 7, gf_dim, out_c), out_c, norm=False)
+    return L
+
+
+def discriminator_param_specs(df_dim=64, in_c=3, segment_class=34):
+    """Creation order of discriminator (module.py:272-318)."""
+    L = []
+
+    def conv(name, shape, norm=True):
+        L.append((name + "_w", shape))
+        L.append((name + "_b", (shape[-1],)))
+        if norm:
+            L.append((name + "_g", (shape[-1],)))
+            L.append((name + "_beta", (shape[-1],)))
+
+    conv("h0", (3, 3, in_c, df_dim), norm=False)
+    conv("h1", (3, 3, df_dim, df_dim * 2))
+    conv("h2", (3, 3, df_dim * 2, df_dim * 4))
+    conv("h3", (3, 3, df_dim * 4, df_dim * 8))
+    conv("h31", (3, 3, df_dim * 8, df_dim * 8))
+    conv("h32", (3, 3, df_dim * 8, df_dim * 8))
+    conv("h33", (3, 3, df_dim * 8, df_dim * 8))
+    conv("h4", (3, 3, df_dim * 8, segment_class), norm=False)
+    return L
+
+
+# ----------------------------------------------------------------------------- layer engine
+class _ConvUnit:
+    """One Conv2D / Conv2DTranspose call site, optionally followed by InstanceNorm (+act, +residual),
+    or by a fused activation when there is no norm.  Stateless w.r.t. activations: forward returns a
+    record that backward consumes, so one network can be applied several times per step."""
+
+    def __init__(self, net, name, kind, stride=1, padding="VALID", reflect=0, norm=True, act=A.ACT_NONE, leak=0.0):
+        self.net, self.name, self.kind = net, name, kind            # kind: "conv" | "deconv"
+        self.stride, self.padding, self.reflect = stride, padding, reflect
+        self.norm, self.act, self.leak = norm, act, leak
+        shape = net.P.index[name + "_w"][2]
+        self.R, self.S = shape[0], shape[1]
+        if kind == "conv":
+            self.cin, self.cout = shape[2], shape[3]
+        else:                                                       # (kh,kw,out,in)
+            self.cout, self.cin = shape[2], shape[3]
+        self._packed = (-1, None, None)
+
+    def geom(self, x):
+        N, H, W, Cp = x.shape
+        assert Cp == K.cpad(self.cin), (self.name, Cp, self.cin)
+        if self.kind == "conv":
+            return K.conv_geom(N, H, W, Cp, K.cpad(self.cout), self.R, self.S, self.stride, self.padding, self.reflect, x.dtype)
+        return K.deconv_geom(N, H, W, Cp, K.cpad(self.cout), self.R, self.S, self.stride, x.dtype)
+
+    def packed(self, dtype):
+        P = self.net.P
+        key = (P.version, dtype)
+        if self._packed[0] != key:
+            w = P.p(self.name + "_w")
+            if self.kind == "conv":
+                wf, wd = K.pack_weights(w, K.cpad(self.cin), K.cpad(self.cout), dtype)
+            else:   # equivalent conv: C = deconv out, K = deconv in -> the stored kernel is already its HWIO
+                wf, wd = K.pack_weights(w, K.cpad(self.cout), K.cpad(self.cin), dtype)
+            self._packed = (key, wf, wd)
+        return self._packed[1], self._packed[2]
+
+    def forward(self, x, residual=None):
+        P, n = self.net.P, self.name
+        g = self.geom(x)
+        wf, wd = self.packed(x.dtype)
+        fused_act = A.ACT_NONE if self.norm else self.act
+        if self.kind == "conv":
+            xc = K.conv_fwd(g, x, wf, P.p(n + "_b"), fused_act, self.leak)
+        else:
+            xc = K.deconv_fwd(g, x, wd, P.p(n + "_b"), fused_act, self.leak)
+        if not self.norm:
+            return xc, (g, x, xc, None)
+        y, stats = K.instnorm_fwd(xc, P.p(n + "_g"), P.p(n + "_beta"), residual, self.net.eps, self.act, self.leak)
+        return y, (g, x, xc, stats)
+
+    def backward(self, rec, dy, want_dx=True, param_grads=True, gbuf=None):
+        P, n = self.net.P, self.name
+        g, x, xc, stats = rec
+        wf, wd = self.packed(x.dtype)
+        if self.norm:
+            if param_grads:
+                dg, db = P.g(n + "_g", buf=gbuf), P.g(n + "_beta", buf=gbuf)
+            else:   # gradients w.r.t. gamma/beta not wanted: send them to scratch
+                dg = db = self.net.scratch_vec(K.cpad(self.cout))
+            dxc = K.instnorm_bwd(dy, xc, P.p(n + "_g"), P.p(n + "_beta"), stats, dg, db, param_grads, self.act, self.leak)
+            # the conv bias feeds an InstanceNorm: its gradient is identically 0 -> left at 0
+        else:
+            dxc = K.act_bwd(dy, xc, self.act, self.leak) if self.act != A.ACT_NONE else dy
+            if param_grads:
+                K.bias_grad(dxc, P.g(n + "_b", buf=gbuf), accumulate=True)
+        if param_grads:
+            (K.conv_wgrad if self.kind == "conv" else K.deconv_wgrad)(g, x, dxc, P.g(n + "_w", buf=gbuf), accumulate=True)
+        if not want_dx:
+            return None
+        return K.conv_dgrad(g, dxc, wd) if self.kind == "conv" else K.deconv_dgrad(g, dxc, wf)
+
+
+class _Net:
+    def __init__(self, specs, dtype, device, eps, seed):
+        self.dtype = dtype
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("sggan networks run on the MI355X HIP path only (device must be a cuda/hip device)")
+        A.lib()                                      # fail loudly if the extension is missing
+        self.eps = eps
+        self.P = ParamStore(specs, self.device)
+        if seed is not None:
+            self.P.init_keras(seed)
+        self._scratch = None
+        self._tv = None
+
+    def scratch_vec(self, n):
+        if self._scratch is None or self._scratch.numel() < n:
+            self._scratch = torch.zeros(max(n, 1024), dtype=torch.float32, device=self.device)
+        return self._scratch[:n]
+
+    # reference-style accessors (model.py:196-200 use .trainable_variables)
+    @property
+    def trainable_variables(self):
+        """Real-shaped views into the flat parameter buffer, in Keras creation order."""
+        if self._tv is None:
+            self._tv = [self.P.p(n, padded=False) for n in self.P.names()]
+        return self._tv
+
+    def requires_grad_(self, flag=True):
+        """Opt the parameter views into torch autograd (only needed by tape-style callers of __call__)."""
+        for v in self.trainable_variables:
+            v.requires_grad_(flag)
+        return self
+
+    def to_internal(self, x):
+        """(N,H,W,C_real) float32 -> channel-padded activation tensor in the network dtype (no-op if already internal)."""
+        if x.dtype == self.dtype and x.shape[-1] % A.CPAD == 0:
+            return x
+        return K.pad_channels(x.to(device=self.device, dtype=torch.float32).contiguous(), K.cpad(x.shape[-1]), self.dtype)
+
+
+class Generator(_Net):
+    """generator_resnet (module.py:219-269): c7s1-64, d128, d256, 9 x R256, u128, u64, c7s1-3 + tanh."""
+
+    def __init__(self, gf_dim=64, in_c=3, out_c=3, n_blocks=9, dtype=torch.bfloat16, device="cuda", eps=1e-3, seed=19):
+        super().__init__(generator_param_specs(gf_dim, in_c, out_c, n_blocks), dtype, device, eps, seed)
+        self.in_c, self.out_c, self.n_blocks = in_c, out_c, n_blocks
+        U = lambda *a, **k: _ConvUnit(self, *a, **k)
+        self.c1 = U("c1", "conv", reflect=3, act=A.ACT_RELU)                       # :230-234
+        self.c2 = U("c2", "conv", stride=2, padding="SAME", act=A.ACT_RELU)        # :236-238
+        self.c3 = U("c3", "conv", stride=2, padding="SAME", act=A.ACT_RELU)        # :240-242
+        self.blocks = [(U(f"r{i}a", "conv", reflect=1, act=A.ACT_RELU),            # residule_block :208-217
+                        U(f"r{i}b", "conv", reflect=1, act=A.ACT_NONE)) for i in range(1, n_blocks + 1)]
+        self.d1 = U("d1", "deconv", stride=2, act=A.ACT_RELU)                      # :254-256
+        self.d2 = U("d2", "deconv", stride=2, act=A.ACT_RELU)                      # :258-260
+        self.out = U("out", "conv", reflect=3, norm=False, act=A.ACT_TANH)         # :262-265
+
+    def forward(self, x):
+        """x: internal (N,H,W,8).  Returns (fake internal (N,H,W,8), tape)."""
+        tape = []
+        h = x
+        for u in (self.c1, self.c2, self.c3):
+            h, r = u.forward(h)
+            tape.append(r)
+        for ua, ub in self.blocks:
+            y, ra = ua.forward(h)
+            h, rb = ub.forward(y, residual=h)                 # IN(conv(y)) + x   (:216-217)
+            tape.append((ra, rb))
+        for u in (self.d1, self.d2, self.out):
+            h, r = u.forward(h)
+            tape.append(r)
+        return h, tape
+
+    def backward(self, tape, dy, want_dx=False, param_grads=True, gbuf=None):
+        nb = self.n_blocks
+        d = dy
+        for u, r in zip((self.out, self.d2, self.d1), (tape[5 + nb], tape[4 + nb], tape[3 + nb])):
+            d = u.backward(r, d, True, param_grads, gbuf)
+        for (ua, ub), (ra, rb) in zip(reversed(self.blocks), reversed(tape[3:3 + nb])):
+            t = ub.backward(rb, d, True, param_grads, gbuf)
+            t = ua.backward(ra, t, True, param_grads, gbuf)
+            d = K.add(t, d)                                   # gradient of the skip connection
+        d = self.c3.backward(tape[2], d, True, param_grads, gbuf)
+        d = self.c2.backward(tape[1], d, True, param_grads, gbuf)
+        return self.c1.backward(tape[0], d, want_dx, param_grads, gbuf)
+
+    def __call__(self, x):
+        """Drop-in for ``self.generator(self.real_A)`` (model.py:175): NHWC float32 in, NHWC float32 out."""
+        return _apply_net(self, x)
+
+    def _run(self, x):
+        y, tape = self.forward(self.to_internal(x))
+        return K.unpad_channels(y, self.out_c), tape
+
+    def _run_backward(self, tape, dy_real, gbuf, want_dx):
+        dy = K.pad_channels(dy_real.contiguous(), K.cpad(self.out_c), self.dtype)
+        dx = self.backward(tape, dy, want_dx, True, gbuf)
+        return None if dx is None else K.unpad_channels(dx, self.in_c)
+
+
+class Discriminator(_Net):
+    """discriminator (module.py:272-318): 8 convs, mask multiply, channel sum."""
+
+    def __init__(self, df_dim=64, in_c=3, segment_class=34, dtype=torch.bfloat16, device="cuda", eps=1e-3, leak=0.3, seed=20):
+        super().__init__(discriminator_param_specs(df_dim, in_c, segment_class), dtype, device, eps, seed)
+        self.in_c, self.segment_class = in_c, segment_class
+        U = lambda *a, **k: _ConvUnit(self, *a, act=A.ACT_LRELU, leak=leak, **k)
+        self.units = [U("h0", "conv", stride=2, padding="SAME", norm=False),      # :284-285
+                      U("h1", "conv", stride=2, padding="SAME"),                  # :287-289
+                      U("h2", "conv", stride=2, padding="SAME"),                  # :291-293
+                      U("h3", "conv", stride=1, padding="SAME"),                  # :295-297
+                      U("h31", "conv", stride=2, padding="VALID"),                # :299-301
+                      U("h32", "conv", stride=2, padding="VALID"),                # :303-305
+                      U("h33", "conv", stride=1, padding="VALID")]                # :307-309
+        self.h4 = _ConvUnit(self, "h4", "conv", stride=1, padding="SAME", norm=False, act=A.ACT_NONE)   # :311
+
+    def forward(self, x, mask):
+        """x internal (N,H,W,8); mask f32 (N,mh,mw,segment_class).  Returns (logits f32 (N,mh,mw,1), tape)."""
+        tape = []
+        h = x
+        for u in self.units:
+            h, r = u.forward(h)
+            tape.append(r)
+        h4, r = self.h4.forward(h)
+        tape.append(r)
+        mask = mask.to(device=self.device, dtype=torch.float32).contiguous()
+        out = K.mask_reduce_fwd(h4, mask, self.segment_class)                    # :312-314
+        tape.append((mask, tuple(h4.shape)))
+        return out, tape
+
+    def backward(self, tape, dlogits, want_dx=False, param_grads=True, gbuf=None):
+        mask, h4_shape = tape[-1]
+        d = K.mask_reduce_bwd(dlogits.contiguous(), mask, h4_shape, self.dtype, self.segment_class)
+        d = self.h4.backward(tape[-2], d, True, param_grads, gbuf)
+        for i in range(len(self.units) - 1, -1, -1):
+            d = self.units[i].backward(tape[i], d, want_dx or i > 0, param_grads, gbuf)
+        return d
+
+    def out_hw(self, H, W):
+        """Spatial size of the h4 map for an HxW input (deviation D1: the mask grid to use above 128x128)."""
+        def sz(n):
+            for _ in range(3):
+                n = -(-n // 2)
+            n = (n - 3) // 2 + 1
+            n = (n - 3) // 2 + 1
+            return n - 2
+        return sz(H), sz(W)
+
+    def __call__(self, inputs):
+        """Drop-in for ``self.discriminator([image, mask])`` (model.py:186-188)."""
+        x, mask = inputs
+        return _apply_net(self, x, mask)
+
+    def _run(self, x, mask):
+        return self.forward(self.to_internal(x), mask)
+
+    def _run_backward(self, tape, dlogits, gbuf, want_dx):
+        dx = self.backward(tape, dlogits, want_dx, True, gbuf)
+        return None if dx is None else K.unpad_channels(dx, self.in_c)
+
+
+# ----------------------------------------------------------------------------- autograd facade
+class _NetFn(torch.autograd.Function):
+    """Lets ``generator(x)`` / ``discriminator([x, mask])`` be used under torch autograd (tape-style
+    callers like model.py:170-197).  The training loop of ``sggan`` does not go through this."""
+
+    @staticmethod
+    def forward(ctx, net, mask, x, *params):
+        y, tape = net._run(x) if mask is None else net._run(x, mask)
+        ctx.net, ctx.tape = net, tape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        net = ctx.net
+        gbuf = torch.zeros_like(net.P.grad)
+        dx = net._run_backward(ctx.tape, dy.to(torch.float32), gbuf, ctx.needs_input_grad[2])
+        grads = tuple(net.P.g(n, buf=gbuf) for n in net.P.names())
+        return (None, None, dx) + grads
+
+
+def _apply_net(net, x, mask=None):
+    x = torch.as_tensor(x)
+    if x.device != net.device:
+        x = x.to(net.device)
+    params = net.trainable_variables
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+        return _NetFn.apply(net, mask, x, *params)
+    y, _ = net._run(x) if mask is None else net._run(x, mask)
+    return y
+
+
+def generator_resnet(**kw) -> Generator:
+    """module.py:219 -- returns a callable ``G(x)``; keyword dims default to the reference constants."""
+    return Generator(**kw)
+
+
+def discriminator(**kw) -> Discriminator:
+    """module.py:272 -- returns a callable ``D([x, mask])``."""
+    return Discriminator(**kw)

@@ -1,0 +1,285 @@
+"""GPU parity tests, op level: every HIP kernel behind the C ABI vs the CPU oracle on seeded inputs.
+
+float32 path: rtol 1e-4 (fp32 kernels vs fp64 oracle); bfloat16 path: 2e-2 of the
+tensor's scale; integer paths: bit exact.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sggan_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def sg():
+    import sggan_amd
+    import sggan_amd.kernels  # noqa: F401
+    import sggan_amd.segment_class  # noqa: F401
+    assert os.path.exists(sggan_amd.LIB_PATH)
+    return sggan_amd
+
+
+def V(a):
+    return O.Var(np.asarray(a, np.float64))
+
+
+def close(got, exp, dtype, what="", scale=None):
+    got = np.asarray(got, np.float64)
+    exp = np.asarray(exp, np.float64)
+    assert got.shape == exp.shape, (what, got.shape, exp.shape)
+    s = scale if scale is not None else max(np.abs(exp).max(), 1e-6)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    err = np.abs(got - exp).max() / s
+    assert err < tol, f"{what}: max err {err:.3e} of scale {s:.3e} (tol {tol})"
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(a, np.float32)).to("cuda").to(dtype)
+
+
+DT = [torch.float32, torch.bfloat16]
+
+# (name, R, stride, padding, Cin, Cout, H, W)
+CONV_CASES = [
+    ("res3x3_reflect", 3, 1, "REFLECT-1", 16, 24, 9, 11),
+    ("res3x3_reflect_big", 3, 1, "REFLECT-1", 128, 128, 12, 10),
+    ("stem7x7_reflect", 7, 1, "REFLECT-3", 3, 16, 12, 13),
+    ("head7x7_reflect", 7, 1, "REFLECT-3", 16, 3, 10, 9),
+    ("same_s2_even", 3, 2, "SAME", 8, 16, 12, 16),
+    ("same_s2_odd", 3, 2, "SAME", 16, 8, 11, 13),
+    ("same_s1", 3, 1, "SAME", 32, 34, 5, 13),
+    ("valid_s2_odd", 3, 2, "VALID", 16, 64, 15, 31),
+    ("valid_s2_even", 3, 2, "VALID", 8, 8, 16, 32),
+    ("valid_s1", 3, 1, "VALID", 64, 72, 7, 15),
+    ("d_h0", 3, 2, "SAME", 3, 64, 16, 16),
+    ("wide_k", 3, 1, "SAME", 256, 136, 6, 6),
+]
+
+
+@pytest.mark.parametrize("dtype", DT, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_fwd_bwd(sg, case, dtype):
+    _, R, stride, padding, Ci, Co, H, W = case
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(case[0].encode()))
+    N = 2
+    q = (lambda a: dev(a, dtype).float().cpu().numpy().astype(np.float64))      # inputs rounded to the storage dtype
+    x = q(rng.standard_normal((N, H, W, Ci)))
+    w = q(rng.standard_normal((R, R, Ci, Co)) / np.sqrt(R * R * Ci))
+    b = rng.standard_normal(Co).astype(np.float32).astype(np.float64)
+    pad, refl = ("VALID", int(padding.split("-")[1])) if padding.startswith("REFLECT") else (padding, 0)
+    t = O.Tape()
+    vx, vw, vb = V(x), V(w), V(b)
+    y = O.conv2d(t, vx, vw, vb, stride, pad, refl)
+    dy = q(rng.standard_normal(y.v.shape))
+    t.backward([(y, dy)])
+
+    tx = dev(x, dtype).requires_grad_(True)
+    tw = dev(w).requires_grad_(True)
+    tb = dev(b).requires_grad_(True)
+    ty = sg.conv2d(tx, tw, tb, stride=stride, padding=padding)
+    close(ty.float().cpu().numpy(), y.v, dtype, "y")
+    ty.backward(dev(dy, dtype))
+    close(tx.grad.float().cpu().numpy(), vx.g, dtype, "dx")
+    close(tw.grad.cpu().numpy(), vw.g, dtype, "dw")
+    close(tb.grad.cpu().numpy(), vb.g, dtype, "db")
+
+
+DECONV_CASES = [("d1_like", 16, 8, 6, 5), ("d2_like", 24, 16, 4, 8), ("wide", 128, 64, 5, 7), ("odd_c", 8, 3, 3, 3)]
+
+
+@pytest.mark.parametrize("dtype", DT, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", DECONV_CASES, ids=[c[0] for c in DECONV_CASES])
+def test_deconv2d_fwd_bwd(sg, case, dtype):
+    _, Ci, Co, H, W = case
+    rng = np.random.default_rng(11)
+    q = (lambda a: dev(a, dtype).float().cpu().numpy().astype(np.float64))
+    x = q(rng.standard_normal((2, H, W, Ci)))
+    w = q(rng.standard_normal((3, 3, Co, Ci)) / np.sqrt(9 * Ci))
+    b = rng.standard_normal(Co).astype(np.float32).astype(np.float64)
+    t = O.Tape()
+    vx, vw, vb = V(x), V(w), V(b)
+    y = O.deconv2d(t, vx, vw, vb, 2)
+    dy = q(rng.standard_normal(y.v.shape))
+    t.backward([(y, dy)])
+    tx, tw, tb = dev(x, dtype).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    ty = sg.deconv2d(tx, tw, tb, stride=2)
+    assert tuple(ty.shape) == (2, 2 * H, 2 * W, Co)
+    close(ty.float().cpu().numpy(), y.v, dtype, "y")
+    ty.backward(dev(dy, dtype))
+    close(tx.grad.float().cpu().numpy(), vx.g, dtype, "dx")
+    close(tw.grad.cpu().numpy(), vw.g, dtype, "dw")
+    close(tb.grad.cpu().numpy(), vb.g, dtype, "db")
+
+
+@pytest.mark.parametrize("dtype", DT, ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape,act", [((2, 9, 7, 16), None), ((2, 32, 40, 64), "relu"), ((3, 17, 19, 40), "lrelu"),
+                                       ((2, 1, 1, 512), "lrelu"), ((1, 64, 64, 8), "relu"), ((2, 5, 13, 520), None)])
+def test_instance_norm_fwd_bwd(sg, shape, act, dtype):
+    rng = np.random.default_rng(5)
+    q = (lambda a: dev(a, dtype).float().cpu().numpy().astype(np.float64))
+    C_ = shape[-1]
+    x = q(rng.standard_normal(shape) * 1.5 + 0.3)
+    g = (1 + 0.2 * rng.standard_normal(C_)).astype(np.float32).astype(np.float64)
+    b = (0.2 * rng.standard_normal(C_)).astype(np.float32).astype(np.float64)
+    t = O.Tape()
+    vx, vg, vb = V(x), V(g), V(b)
+    y = O.instance_norm(t, vx, vg, vb, 1e-3)
+    if act == "relu":
+        y = O.relu(t, y)
+    elif act == "lrelu":
+        y = O.lrelu(t, y, 0.3)
+    dy = q(rng.standard_normal(shape))
+    t.backward([(y, dy)])
+    tx, tg, tb = dev(x, dtype).requires_grad_(True), dev(g).requires_grad_(True), dev(b).requires_grad_(True)
+    ty = sg.instance_norm(tx, tg, tb, eps=1e-3, act=act, leak=0.3)
+    close(ty.float().cpu().numpy(), y.v, dtype, "y")
+    ty.backward(dev(dy, dtype))
+    close(tx.grad.float().cpu().numpy(), vx.g, dtype, "dx", scale=max(np.abs(vx.g).max(), 1e-3))
+    close(tg.grad.cpu().numpy(), vg.g, dtype, "dgamma", scale=max(np.abs(vg.g).max(), 1.0))
+    close(tb.grad.cpu().numpy(), vb.g, dtype, "dbeta", scale=max(np.abs(vb.g).max(), 1.0))
+
+
+def test_instance_norm_residual_and_eps(sg):
+    from sggan_amd import kernels as K
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((2, 8, 8, 16)); r = rng.standard_normal((2, 8, 8, 16))
+    g = np.ones(16); b = np.zeros(16)
+    for eps in (1e-3, 1e-5):                                      # live tfa eps and the ops.py:19 spec
+        t = O.Tape()
+        y = O.add(t, O.instance_norm(t, V(x), V(g), V(b), eps), V(r))
+        ty, _ = K.instnorm_fwd(dev(x), dev(g), dev(b), dev(r), eps)
+        close(ty.cpu().numpy(), y.v, torch.float32, f"eps={eps}")
+
+
+@pytest.mark.parametrize("dtype", DT, ids=["f32", "bf16"])
+def test_activations(sg, dtype):
+    rng = np.random.default_rng(4)
+    x = dev(rng.standard_normal((2, 5, 7, 24)), dtype)
+    xf = x.float().cpu().numpy().astype(np.float64)
+    for fn, ref, dref in ((lambda t: sg.lrelu(t, 0.3), lambda a: np.where(a > 0, a, 0.3 * a), lambda a: np.where(a > 0, 1, 0.3)),
+                          (lambda t: sg.lrelu(t, 0.2), lambda a: np.maximum(a, 0.2 * a), lambda a: np.where(a > 0, 1, 0.2)),
+                          (sg.relu, lambda a: np.maximum(a, 0), lambda a: (a > 0) * 1.0),
+                          (sg.tanh, np.tanh, lambda a: 1 - np.tanh(a) ** 2)):
+        tx = x.clone().requires_grad_(True)
+        y = fn(tx)
+        close(y.float().cpu().numpy(), ref(xf), dtype, "act")
+        y.backward(torch.ones_like(y))
+        close(tx.grad.float().cpu().numpy(), dref(xf), dtype, "dact")
+
+
+def test_seg_class_map_reference_fixtures_bit_exact(sg):
+    sc = sg.segment_class
+    z = np.load(os.path.join(G, "segclass_gta.npz"))
+    for d in ("trainA", "trainB"):
+        for key in ("crop_rgb", "crop_rgba"):                      # alpha ignored (segment_class.py:97 img[x,y,:3])
+            got = sc.preprocess(z[f"{d}_{key}"]).cpu().numpy()
+            assert np.array_equal(got, z[f"{d}_crop_expected"]), (d, key)
+    # every table entry, near misses, default
+    cols = np.array([k for k, _ in O.CITYSCAPE_MAP] + [(0, 0, 0), (128, 64, 129), (129, 64, 128), (255, 255, 255)], np.uint8)
+    exp = np.array([v for _, v in O.CITYSCAPE_MAP] + [0, 0, 0, 0], np.uint8)
+    assert np.array_equal(sc.preprocess(cols[None]).cpu().numpy()[0], exp)
+    assert dict(sc.cityscape()) == {k: v for k, v in O.CITYSCAPE_MAP}
+    # full Cityscapes-size image: random palette field, exact equality with the oracle
+    rng = np.random.default_rng(0)
+    pal = np.array([k for k, _ in O.CITYSCAPE_MAP] + [(0, 0, 0), (20, 20, 20), (111, 74, 0)], np.uint8)
+    img = pal[rng.integers(0, len(pal), (1024, 2048))]
+    got = sc.preprocess(img).cpu().numpy()
+    assert np.array_equal(got, O.seg_class_map(img))
+    assert sc.preprocess(np.zeros((0, 4, 3), np.uint8)).shape == (0, 4)
+
+
+def test_onehot_resample_bit_exact(sg):
+    sc = sg.segment_class
+    rng = np.random.default_rng(1)
+    for (H, W, oh, ow, nc) in ((128, 128, 4, 4, 34), (1024, 2048, 5, 13, 34), (256, 512, 8, 15, 8), (37, 53, 1, 1, 8), (16, 16, 16, 16, 8)):
+        idx = rng.integers(0, nc, (2, H, W)).astype(np.uint8)
+        got = sc.one_hot_mask(idx, oh, ow, nc).cpu().numpy()
+        exp = np.stack([O.mask_from_index(i, nc, oh, ow) for i in idx])
+        assert np.array_equal(got, exp), (H, W, oh, ow)
+        assert np.array_equal(got.sum(-1), np.ones((2, oh, ow)))
+
+
+@pytest.mark.parametrize("dtype", DT, ids=["f32", "bf16"])
+def test_mask_reduce(sg, dtype):
+    from sggan_amd import kernels as K
+    rng = np.random.default_rng(8)
+    for hh, hw, mh, mw in ((1, 1, 4, 4), (5, 13, 5, 13)):
+        h4 = rng.standard_normal((2, hh, hw, 34))
+        h4p = np.pad(h4, ((0, 0),) * 3 + ((0, 6),))
+        th = dev(h4p, dtype)
+        h4q = th.float().cpu().numpy()[..., :34].astype(np.float64)
+        mask = np.stack([O.one_hot(i, 34) for i in rng.integers(0, 34, (2, mh, mw))]).astype(np.float64)
+        t = O.Tape()
+        vh = V(h4q)
+        y = O.mask_reduce(t, vh, mask)
+        dy = rng.standard_normal(y.v.shape)
+        t.backward([(y, dy)])
+        out = K.mask_reduce_fwd(th, dev(mask), 34)
+        close(out.cpu().numpy(), y.v, torch.float32, "mask fwd")
+        dh = K.mask_reduce_bwd(dev(dy), dev(mask), tuple(th.shape), dtype, 34)
+        close(dh.float().cpu().numpy()[..., :34], vh.g, dtype, "mask bwd")
+        assert float(dh.float()[..., 34:].abs().max()) == 0.0
+
+
+def test_losses(sg):
+    from sggan_amd import kernels as K
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2, 4, 4, 1)) * 3
+    loss = torch.zeros(1, device="cuda")
+    for label in (1.0, 0.0):
+        t = O.Tape(); vx = V(x); l = O.bce_logits_mean(t, vx, label); t.backward([(l, 1.0)])
+        dx = torch.empty(x.shape, device="cuda")
+        K.bce_logits(dev(x), label, loss, dx)
+        assert abs(loss.item() - l.v) < 1e-6 * max(1, abs(l.v))
+        close(dx.cpu().numpy(), vx.g, torch.float32, "dbce")
+    K.bce_logits(dev(np.zeros(7)), 1.0, loss, None)
+    assert abs(loss.item() - np.log(2)) < 1e-7
+    K.bce_logits(dev(np.zeros(7)), 0.0, loss, None, accumulate_loss=True)
+    assert abs(loss.item() - 2 * np.log(2)) < 1e-6
+    for dtype in DT:
+        a = np.zeros((2, 16, 16, 8)); b = np.zeros((2, 16, 16, 8))
+        a[..., :3] = rng.uniform(0, 1, (2, 16, 16, 3)); b[..., :3] = np.tanh(rng.standard_normal((2, 16, 16, 3)))
+        ta, tb = dev(a, dtype), dev(b, dtype)
+        aq, bq = ta.float().cpu().numpy().astype(np.float64)[..., :3], tb.float().cpu().numpy().astype(np.float64)[..., :3]
+        t = O.Tape(); vb = V(bq); l = O.l1_mean(t, aq, vb); t.backward([(l, 100.0)])
+        db = torch.empty_like(tb)
+        K.l1_loss(ta, tb, 3, loss, db, weight=100.0)
+        assert abs(loss.item() - 100 * l.v) < 1e-4 * 100 * l.v
+        close(db.float().cpu().numpy()[..., :3], vb.g, dtype, "dl1")
+        assert float(db.float()[..., 3:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("eps", [1e-7, 1e-2])
+def test_adam_tf_form(sg, eps):
+    from sggan_amd import kernels as K
+    rng = np.random.default_rng(3)
+    n = 10007
+    th, g = rng.standard_normal(n), rng.standard_normal(n) * 0.1
+    m, v = np.zeros(n), np.zeros(n)
+    tth, tm, tv = dev(th), dev(m), dev(v)
+    for t in (1, 2, 3):
+        g = rng.standard_normal(n) * 0.1
+        th, m, v = O.adam_tf(th, g.astype(np.float32).astype(np.float64), m, v, t, 1e-3, 0.5, 0.999, eps)
+        K.adam(tth, dev(g), tm, tv, t, 1e-3, 0.5, 0.999, eps)
+    assert np.abs(tth.cpu().numpy() - th).max() < 2e-6
+    # step-1 known answer with g = 1: -lr*sqrt(1-b2)/(sqrt(1-b2)+eps)  (Keras form, not torch's)
+    one = dev(np.zeros(4)); K.adam(one, dev(np.ones(4)), dev(np.zeros(4)), dev(np.zeros(4)), 1, 1e-3, 0.5, 0.999, eps)
+    assert abs(one[0].item() + 1e-3 * np.sqrt(1e-3) / (np.sqrt(1e-3) + eps)) < 1e-9
+
+
+def test_abi_rejects_bad_arguments(sg):
+    from sggan_amd import kernels as K
+    with pytest.raises(Exception):
+        K.conv_geom(1, 4, 4, 8, 8, 3, 3, 1, "VALID", 5, torch.float32)       # reflect pad >= size
+    with pytest.raises(Exception):
+        K.conv_geom(1, 2, 2, 8, 8, 3, 3, 1, "VALID", 0, torch.float32)       # empty output
+    with pytest.raises(sg.SggError):
+        K.mask_reduce_fwd(torch.zeros(1, 2, 2, 40, device="cuda"), torch.zeros(1, 3, 3, 34, device="cuda"), 34)
+    with pytest.raises(TypeError):
+        K.act_fwd(torch.zeros(8, device="cuda", dtype=torch.float16), 1)

@@ -1,0 +1,188 @@
+"""GPU parity tests, network / train-step level, against the committed oracle fixtures
+(tests/golden/, PARITY UNPINNED floats -- see oracle/sggan_oracle.py) and size-independent properties."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sggan_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def sg():
+    import sggan_amd
+    return sggan_amd
+
+
+def load_small():
+    z = np.load(os.path.join(G, "oracle_small.npz"))
+    PG = {k[3:]: z[k] for k in z.files if k.startswith("PG/")}
+    PD = {k[3:]: z[k] for k in z.files if k.startswith("PD/")}
+    real = z["real_A_u8"].astype(np.float32) / np.float32(255)
+    seg = z["seg_A_u8"].astype(np.float32) / np.float32(255)
+    mask = np.stack([O.one_hot(i, 34) for i in z["mask_idx"]]).astype(np.float32)
+    return z, PG, PD, real, seg, mask
+
+
+def small_model(sg, dtype):
+    m = sg.sggan(sg.default_args(ngf=8, ndf=8, n_blocks=2, dtype=dtype))
+    z, PG, PD, real, seg, mask = load_small()
+    m.generator.P.load(PG)
+    m.discriminator.P.load(PD)
+    m.real_A, m.seg_A, m.mask_A = real, seg, mask
+    return m, z
+
+
+def rel(got, exp):
+    got, exp = np.asarray(got, np.float64), np.asarray(exp, np.float64)
+    return np.abs(got - exp).max() / max(np.abs(exp).max(), 1e-12)
+
+
+def test_train_step_small_f32_matches_oracle(sg):
+    m, z = small_model(sg, "f32")
+    G_, D_ = m.generator, m.discriminator
+    # gradients are cleared at the start of the NEXT step, so they can be read after this one
+    m.train_step()
+    gl, dl = m.losses()
+    assert abs(gl - float(z["gen_loss"])) < 1e-5 * abs(float(z["gen_loss"]))          # 1e-5 on losses
+    assert abs(dl - float(z["disc_loss"])) < 1e-5 * abs(float(z["disc_loss"]))
+    assert rel(m.fake_A.numpy(), z["fake_A"]) < 1e-4                                  # 1e-4 on images
+    assert rel(m.da_real.cpu().numpy(), z["da_real"]) < 1e-4 and rel(m.da_fake.cpu().numpy(), z["da_fake"]) < 1e-4
+    gG, gD = G_.P.export(G_.P.grad), D_.P.export(D_.P.grad)
+    for k, v in gG.items():
+        e = z["gG/" + k]
+        if k.endswith("_b") and k != "out_b":            # bias before InstanceNorm: exactly 0 here, ~1e-17 in the oracle
+            assert np.abs(v).max() == 0.0 and np.abs(e).max() < 1e-9
+            continue
+        assert rel(v, e) < 2e-4, ("gG", k, rel(v, e))
+    for k, v in gD.items():
+        e = z["gD/" + k]
+        if k.endswith("_b") and k not in ("h0_b", "h4_b"):
+            assert np.abs(v).max() == 0.0 and np.abs(e).max() < 1e-9
+            continue
+        assert rel(v, e) < 2e-4, ("gD", k, rel(v, e))
+    # post-Adam parameters: lr=1e-3 steps of +-lr on O(0.1..1) weights
+    for k, v in G_.P.export().items():
+        if k.endswith("_b") and k != "out_b":
+            continue
+        assert np.abs(v - z["newPG/" + k]).max() < 2e-5, ("newPG", k)
+    for k, v in D_.P.export().items():
+        if k.endswith("_b") and k not in ("h0_b", "h4_b"):
+            continue
+        assert np.abs(v - z["newPD/" + k]).max() < 2e-5, ("newPD", k)
+
+
+def test_train_step_small_bf16_close_to_oracle(sg):
+    m, z = small_model(sg, "bf16")
+    m.train_step()
+    gl, dl = m.losses()
+    assert abs(gl - float(z["gen_loss"])) < 1e-2 * abs(float(z["gen_loss"]))          # bf16 losses within 1e-2
+    assert abs(dl - float(z["disc_loss"])) < 1e-2 * abs(float(z["disc_loss"]))
+    assert np.abs(m.fake_A.numpy() - z["fake_A"]).max() < 6e-2                        # tanh output in [-1,1]
+    gG = m.generator.P.export(m.generator.P.grad)
+    for k in ("c1_w", "r1a_w", "r2b_w", "d1_w", "out_w"):
+        e = z["gG/" + k]
+        assert np.abs(gG[k] - e).max() < 0.08 * np.abs(e).max(), k
+
+
+def test_dropin_callables_and_autograd(sg):
+    """generator(x) / discriminator([x, mask]) keep the reference call conventions (model.py:175,186)."""
+    m, z = small_model(sg, "f32")
+    x = torch.as_tensor(m.real_A).cuda()
+    fake = m.generator(x)
+    assert tuple(fake.shape) == (2, 128, 128, 3) and fake.dtype == torch.float32
+    assert rel(fake.cpu().numpy(), z["fake_A"]) < 1e-4
+    da = m.discriminator([torch.as_tensor(m.seg_A).cuda(), torch.as_tensor(m.mask_A).cuda()])
+    assert tuple(da.shape) == (2, 4, 4, 1) and rel(da.cpu().numpy(), z["da_real"]) < 1e-4
+    # tape-style use: d(mean(D(G(x)))) / d(G params) through both networks
+    m.generator.requires_grad_(True)
+    out = m.discriminator([m.generator(x), torch.as_tensor(m.mask_A).cuda()])
+    out.mean().backward()
+    gw = m.generator.trainable_variables[0].grad
+    assert gw is not None and torch.isfinite(gw).all() and gw.abs().max() > 0
+
+
+def test_full_size_step_f32_matches_oracle_checksums(sg):
+    from tests.golden.make_golden import full_inputs
+    js = json.load(open(os.path.join(G, "oracle_full.json")))
+    PG, PD, real, seg, mask = full_inputs(js["seed"], js["N"], js["H"], js["W"])
+    m = sg.sggan(sg.default_args(dtype="f32"))
+    m.generator.P.load(PG); m.discriminator.P.load(PD)
+    assert m.generator.P.n_real() == 11_388_675 and m.discriminator.P.n_real() == 8_791_970
+    m.real_A, m.seg_A, m.mask_A = real, seg, mask
+    m.train_step()
+    gl, dl = m.losses()
+    assert abs(gl - js["gen_loss"]) < 1e-5 * js["gen_loss"] and abs(dl - js["disc_loss"]) < 1e-5 * js["disc_loss"]
+    f = m.fake_A.numpy()
+    assert abs(f.mean() - js["fake_A_mean"]) < 1e-5 and np.abs(f.ravel()[:8] - np.array(js["fake_A_first8"])).max() < 1e-4
+    assert rel(m.da_real.cpu().numpy().ravel(), js["da_real"]) < 1e-4 and rel(m.da_fake.cpu().numpy().ravel(), js["da_fake"]) < 1e-4
+    norm = lambda d: {k: float(np.sqrt((v.astype(np.float64) ** 2).sum())) for k, v in d.items()}
+    for got, exp, skip in ((norm(m.generator.P.export(m.generator.P.grad)), js["gG_norm"], ("out_b",)),
+                           (norm(m.discriminator.P.export(m.discriminator.P.grad)), js["gD_norm"], ("h0_b", "h4_b"))):
+        for k, e in exp.items():
+            if k.endswith("_b") and k not in skip:
+                continue
+            assert abs(got[k] - e) < 5e-4 * max(e, 1e-8), (k, got[k], e)
+
+
+def _rand_inputs(N, H, W, D, seed):
+    g = torch.Generator().manual_seed(seed)
+    real = torch.rand((N, H, W, 3), generator=g)
+    seg = torch.rand((N, H, W, 3), generator=g)
+    mh, mw = D.out_hw(H, W)
+    mh, mw = (4, 4) if (mh, mw) == (1, 1) else (mh, mw)
+    idx = torch.randint(0, 34, (N, mh, mw), generator=g)
+    mask = torch.nn.functional.one_hot(idx, 34).float()
+    return real, seg, mask
+
+
+def test_step_is_deterministic_and_dp_equivalent(sg):
+    """Two properties that hold at any size: (1) bitwise reproducibility (fixed-order reductions, no atomics);
+    (2) data parallelism == batch concatenation: mean of the two half-batch gradients equals the full-batch one
+    (InstanceNorm is per-sample; every loss is a mean -- SURVEY.md 8(e))."""
+    args = sg.default_args(ngf=16, ndf=16, n_blocks=3, dtype="f32")
+    runs = []
+    for _ in range(2):
+        m = sg.sggan(args)
+        m.real_A, m.seg_A, m.mask_A = _rand_inputs(4, 256, 256, m.discriminator, 7)
+        m.train_step()
+        runs.append((m.generator.P.flat.clone(), m.discriminator.P.flat.clone(), m._loss.clone(),
+                     m.generator.P.grad.clone(), m.discriminator.P.grad.clone()))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    full_gG, full_gD = runs[0][3], runs[0][4]
+    real, seg, mask = _rand_inputs(4, 256, 256, m.discriminator, 7)
+    acc_G, acc_D = torch.zeros_like(full_gG), torch.zeros_like(full_gD)
+    for sl in (slice(0, 2), slice(2, 4)):
+        h = sg.sggan(args)
+        h.real_A, h.seg_A, h.mask_A = real[sl], seg[sl], mask[sl]
+        h.train_step()
+        acc_G += h.generator.P.grad / 2
+        acc_D += h.discriminator.P.grad / 2
+    assert (acc_G - full_gG).abs().max() < 1e-4 * full_gG.abs().max()
+    assert (acc_D - full_gD).abs().max() < 1e-4 * full_gD.abs().max()
+
+
+def test_bench_size_bf16_step_runs_and_is_sane(sg):
+    """Config 3 shape (N=8 is the bench; N=2 here): 256x512, bf16, D1 mask grid = D's 5x13 map."""
+    m = sg.sggan(sg.default_args(dtype="bf16"))
+    assert m.discriminator.out_hw(256, 512) == (5, 13)
+    m.real_A, m.seg_A, m.mask_A = _rand_inputs(2, 256, 512, m.discriminator, 3)
+    for _ in range(2):
+        m.train_step()
+    gl, dl = m.losses()
+    assert np.isfinite(gl) and np.isfinite(dl) and 0 < dl < 10 and 0 < gl < 200
+    f = m.fake_A.numpy()
+    assert f.shape == (2, 256, 512, 3) and np.abs(f).max() <= 1.0
+    # InstanceNorm invariant on a live activation: per-(n,c) mean 0 / var 1 after the first unit (before ReLU)
+    from sggan_amd import kernels as K
+    x = m.generator.to_internal(m.real_A.cuda())
+    g, xin, xc, stats = m.generator.c1.forward(x)[1]
+    y, _ = K.instnorm_fwd(xc, torch.ones(64, device="cuda"), torch.zeros(64, device="cuda"))
+    yf = y.float()
+    assert yf.mean((1, 2)).abs().max() < 2e-2 and (yf.var((1, 2), unbiased=False) - 1).abs().max() < 5e-2

@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- train-step images/sec of the SG-GAN hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one reference-mode ``train_step`` (model.py:169-200: G fwd, D on real+fake, both losses, both
+gradient sets, both Adam updates) over one synthetic batch that is already resident in HBM.  Workload =
+BASELINE.json configs[2]: 512x256 (W x H) images, batch 8 per GPU, bf16 storage / f32 accumulate, 9-block
+ResNet generator; weak scaling (8 images per GPU), gradients averaged with one RCCL all-reduce per network.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying two extra objects:
+  roofline     -- the dominant kernel (3x3 C=256 residual-block conv forward, implicit GEMM M=N*64*128, N=256,
+                  K=2304): algorithmic FLOPs per launch / its average duration measured with HIP events on the
+                  launch stream inside the timed region, vs the 2.5 PFLOP/s dense bf16 MFMA peak.
+  cpu_baseline -- the PyTorch-CPU float32 restatement of the same step (oracle/torch_restatement.py; "port":
+                  the reference's TF2 path cannot run here) timed on the host cores, N=1 image, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0          # HBM3E spec
+# conv MACs per image, forward: G(H,W) scales with H*W; D from its layer table
+G_GMAC_256x512 = 99.103
+D_GMAC = {(128, 128): 0.599, (256, 256): 2.550, (256, 512): 5.189, (512, 1024): 21.375}
+
+
+def step_gflop_per_image(H, W):
+    g = G_GMAC_256x512 * (H * W) / (256 * 512)
+    d = D_GMAC.get((H, W))
+    if d is None:
+        d = 5.189 * (H * W) / (256 * 512)
+    return 2.0 * (3 * g + 7 * d)          # reference-mode step: 3G + 7D MACs
+
+
+def synthetic_batch(model, N, H, W, seed):
+    """real ~ U[0,1); class-index map = 32x32-px blocks over 16 label ids; seg = palette
+    colour / 255; mask = one-hot of the index map resampled to D's output grid (deviation D1)."""
+    import sggan_amd.segment_class as sc
+    g = torch.Generator().manual_seed(seed)
+    real = torch.rand((N, H, W, 3), generator=g)
+    ids = torch.tensor([0, 1, 3, 4, 7, 8, 11, 17, 20, 21, 22, 23, 24, 25, 26, 33])
+    blocks = ids[torch.randint(0, len(ids), (N, H // 32, W // 32), generator=g)]
+    idx = blocks.repeat_interleave(32, 1).repeat_interleave(32, 2).to(torch.uint8)
+    palette = torch.randint(0, 256, (34, 3), generator=torch.Generator().manual_seed(1234)).float() / 255.0
+    seg = palette[idx.long()]
+    mh, mw = model.discriminator.out_hw(H, W)
+    if (mh, mw) == (1, 1):
+        mh, mw = round(H / 34), round(W / 34)        # the reference's loader grid (utils.py:197-199)
+    mask = sc.one_hot_mask(idx.to(model.device), mh, mw, 34)
+    real_i = model.generator.to_internal(real.to(model.device))
+    seg_i = model.generator.to_internal(seg.to(model.device))
+    return real_i, seg_i, mask, (real, seg, mask.cpu())
+
+
+class EventProfiler:
+    """Times selected launches with torch.cuda events on the current stream (the one kernels.py launches on)."""
+
+    def __init__(self, res_hw=(64, 128)):
+        self.records = {}
+        self.enabled = False
+        self.res_hw = tuple(res_hw)          # spatial size of the residual blocks (H/4, W/4)
+
+    class _Span:
+        def __init__(self, store):
+            self.s, self.e, self.store = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), store
+
+        def start(self):
+            self.s.record()
+
+        def stop(self):
+            self.e.record()
+            self.store.append((self.s, self.e))
+
+    def __call__(self, name, key):
+        if not self.enabled:
+            return None
+        tag = None
+        if name == "conv2d_fwd" and hasattr(key, "desc"):
+            d = key.desc
+            if d.R == 3 and d.C == 256 and d.K == 256 and d.stride == 1 and d.pad_mode == 1:
+                tag = ("res_conv_fwd", d.N * d.Ho * d.Wo, d.K, d.R * d.S * d.C)
+        elif name == "conv2d_bwd_data" and hasattr(key, "desc"):
+            d = key.desc
+            if d.R == 3 and d.C == 256 and d.K == 256 and d.stride == 1 and d.pad_mode == 1:
+                tag = ("res_conv_dgrad", d.N * d.H * d.W, d.C, d.R * d.S * d.K)
+        elif name == "conv2d_bwd_weight" and hasattr(key, "desc"):
+            d = key.desc
+            if d.R == 3 and d.C == 256 and d.K == 256 and d.stride == 1 and d.pad_mode == 1:
+                tag = ("res_conv_wgrad", d.R * d.S * d.C, d.K, d.N * d.Ho * d.Wo)
+        elif name == "instnorm_fwd" and len(key) == 4 and key[3] == 256 and tuple(key[1:3]) == self.res_hw:
+            tag = ("res_instnorm_fwd", key[0] * key[1] * key[2] * key[3])
+        if tag is None:
+            return None
+        return self._Span(self.records.setdefault(tag, []))
+
+    def summary(self):
+        out = {}
+        for tag, evs in self.records.items():
+            ms = [s.elapsed_time(e) for s, e in evs]
+            out[tag] = (float(np.mean(ms)), len(ms))
+        return out
+
+
+def cpu_baseline(H, W, seed, max_seconds=30.0):
+    """The PyTorch-CPU f32 restatement of the same step at N=1 (kind "port"), median of up to 3 steps after 1 warm-up."""
+    from oracle import torch_restatement as T
+    from oracle import sggan_oracle as O
+    rng = np.random.default_rng(seed)
+    PG = O.init_params(O.generator_param_shapes(), rng)
+    PD = O.init_params(O.discriminator_param_shapes(), rng)
+    real = rng.uniform(0, 1, (1, H, W, 3)).astype(np.float32)
+    seg = rng.uniform(0, 1, (1, H, W, 3)).astype(np.float32)
+    mh, mw = O.disc_out_hw(H, W)
+    mask = np.stack([O.one_hot(rng.integers(0, 34, (mh, mw)), 34)]).astype(np.float32)
+    S = T.RefStep(PG, PD, torch.float32)
+    t0 = time.time()
+    S.step(real, seg, mask)                       # warm-up (also bounds the sample)
+    warm = time.time() - t0
+    times = []
+    while len(times) < 3 and (time.time() - t0) + warm < max_seconds:
+        t1 = time.time()
+        S.step(real, seg, mask)
+        times.append(time.time() - t1)
+    if not times:
+        times = [warm]
+    dt = float(np.median(times))
+    return {"value": 1.0 / dt, "unit": "images/sec", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{len(times)} reference-mode steps of N=1 {W}x{H} f32 (PyTorch-CPU restatement of model.py:169-200, "
+                      f"not TF2) after 1 warm-up, median; os.cpu_count()={os.cpu_count()}",
+            "gflops": step_gflop_per_image(H, W) / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    import sggan_amd
+    from sggan_amd import kernels as K
+    model = sggan_amd.sggan(sggan_amd.default_args(dtype=a.dtype, device=f"cuda:{local}", image_height=a.height,
+                                                   image_width=a.width, batch_size=a.batch))
+    if world > 1:
+        model.enable_data_parallel()
+    real, seg, mask, _ = synthetic_batch(model, a.batch, a.height, a.width, 19 + rank)
+    model.real_A, model.seg_A, model.mask_A = real, seg, mask
+
+    prof = EventProfiler((a.height // 4, a.width // 4))
+    K.PROFILE = prof
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        model.train_step()
+    barrier()
+    prof.enabled = (rank == 0) and not a.no_kernel_timing
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        model.train_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof.enabled = False
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    gl, dl = model.losses()
+    if not (np.isfinite(gl) and np.isfinite(dl)):
+        raise SystemExit(f"non-finite losses after the timed region: gen {gl} disc {dl}")
+
+    if rank == 0:
+        images = a.batch * world * a.steps
+        ips = images / elapsed
+        gflop_img = step_gflop_per_image(a.height, a.width)
+        line = {
+            "metric": "train-step images/sec (G+D fwd/bwd) at 512x256", "value": ips, "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: reference-mode train_step (model.py:169-200; 1 G + 1 D, 9-block ResNet G), "
+                                   f"{a.width}x{a.height}, batch {a.batch}/GPU, {a.dtype} storage / f32 accumulate",
+                       "global_batch": a.batch * world, "height": a.height, "width": a.width, "parallelism": f"dp{world}",
+                       "gflop_per_image": gflop_img},
+            "step_tflops": ips * gflop_img / 1e3,
+            "step_frac_of_mfma_peak": ips * gflop_img / 1e3 / (PEAK_BF16_TFLOPS * world),
+            "gen_loss": gl, "disc_loss": dl,
+        }
+        summ = prof.summary()
+        kt = {}
+        for tag, (ms, n) in summ.items():
+            if tag[0].startswith("res_conv"):
+                fl = 2.0 * tag[1] * tag[2] * tag[3]
+                kt[tag[0]] = {"avg_ms": ms, "launches": n, "tflops": fl / (ms * 1e-3) / 1e12, "gflop_per_launch": fl / 1e9}
+            else:
+                by = 3 * tag[1] * (2 if a.dtype == "bf16" else 4)       # 2 reads + 1 write of the tensor
+                kt[tag[0]] = {"avg_ms": ms, "launches": n, "gbs": by / (ms * 1e-3) / 1e9, "mbytes_per_launch": by / 1e6}
+        if "res_conv_fwd" in kt:
+            k = kt["res_conv_fwd"]
+            line["roofline"] = {"bound": "mfma", "kernel": "conv_gemm_kernel<bf16,FWD,128,128> (3x3 C=256 residual-block conv)",
+                                "achieved": k["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                "frac": k["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
+                                "avg_launch_ms": k["avg_ms"], "launches_timed": k["launches"], "gflop_per_launch": k["gflop_per_launch"]}
+        else:
+            line["roofline"] = None
+        if "res_instnorm_fwd" in kt:
+            k = kt["res_instnorm_fwd"]
+            line["roofline_instnorm"] = {"bound": "hbm", "achieved": k["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                         "frac": k["gbs"] / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": k["avg_ms"],
+                                         "note": "3 launches (partial stats, finalize, apply); algorithmic bytes = 2 reads + 1 write"}
+        line["kernels"] = kt
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.height, a.width, 19)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

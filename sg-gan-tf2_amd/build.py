@@ -37,7 +37,12 @@ def build_lib(force=False, verbose=False):
             cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                sys.stderr.write(r.stdout + r.stderr)
+                raise RuntimeError(f"hipcc failed on {src}")
+            if verbose and r.stderr.strip():
+                sys.stderr.write(r.stderr[-4000:])
         return obj
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:

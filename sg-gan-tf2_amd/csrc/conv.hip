@@ -21,8 +21,9 @@
 // The weight fragment is the MFMA A operand and the pixel fragment the B operand, so the accumulator holds
 // D[cout][pixel]: each lane owns 4 consecutive output channels of one pixel = one 8/16-byte NHWC store.
 #include "common.h"
+#include <stdlib.h>
 
-enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_BORDER = 2 };   // BORDER: dgrad of the REFLECT border pixels only
 
 struct ConvArgs {
     const char* src;     // FWD: x (N,H,W,C)    DGRAD: dy (N,Ho,Wo,K)
@@ -76,45 +77,67 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     const int nr = ph < a.R ? (a.R - ph + st - 1) / st : 0;  // taps of this class along r / s
     const int ns = pw < a.S ? (a.S - pw + st - 1) / st : 0;
     const int SC = (MODE == MODE_FWD) ? a.C : a.K;           // reduction channels (source tensor)
+    static_assert(MODE == MODE_FWD || MODE == MODE_DGRAD || MODE == MODE_BORDER, "mode");
     const int DC = (MODE == MODE_FWD) ? a.K : a.C;           // destination channels
     const int cpv = SC / VEC;                                // 16-byte chunks per tap
     const int wrow = a.R * a.S * SC;                         // weight row length (elements)
 
     // ---- destination pixel space of this block ----
+    // FWD: all output pixels.  DGRAD: the pixels of parity class (ph,pw).  BORDER: only the pixels whose gradient
+    // receives mirrored contributions (rows 1..p, H-1-p..H-2 and the same columns), or every pixel when the
+    // image is too small for those bands to be disjoint.
     int hbase = 0, wbase = 0, Hc, Wc;
+    const int p2 = 2 * a.pad_t;
+    const bool ball = (MODE == MODE_BORDER) && (a.H <= p2 + 1 || a.W <= p2 + 1);
+    int Bimg = 0;
     if (MODE == MODE_FWD) { Hc = a.Ho; Wc = a.Wo; }
-    else {
+    else if (MODE == MODE_DGRAD) {
         hbase = ((ph - a.pad_t) % st + st) % st;
         wbase = ((pw - a.pad_l) % st + st) % st;
         Hc = hbase < a.H ? (a.H - hbase + st - 1) / st : 0;
         Wc = wbase < a.W ? (a.W - wbase + st - 1) / st : 0;
-    }
-    const int M = a.N * Hc * Wc;
+    } else { Hc = a.H; Wc = a.W; Bimg = ball ? a.H * a.W : p2 * a.W + (a.H - p2) * p2; }
+    const int M = (MODE == MODE_BORDER) ? a.N * Bimg : a.N * Hc * Wc;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     if (m0 >= M) return;                                     // whole block outside this class (uniform)
+
+    // m -> (image, destination h, destination w); FWD returns the output pixel (ho, wo)
+    auto decode = [&](int m, int& n, int& h, int& w) {
+        if (MODE == MODE_BORDER && !ball) {
+            n = m / Bimg;
+            int q = m - n * Bimg;
+            const int p = a.pad_t;
+            if (q < p2 * a.W) {
+                int hi = q / a.W;
+                w = q - hi * a.W;
+                h = hi < p ? 1 + hi : a.H - 1 - p + (hi - p);
+            } else {
+                q -= p2 * a.W;
+                int hh = q / p2, wi = q - hh * p2;
+                h = hh == 0 ? 0 : (hh == a.H - p2 - 1 ? a.H - 1 : p + hh);
+                w = wi < p ? 1 + wi : a.W - 1 - p + (wi - p);
+            }
+        } else {
+            n = m / (Hc * Wc);
+            int rem = m - n * (Hc * Wc);
+            int hp = rem / Wc;
+            h = hbase + st * hp; w = wbase + st * (rem - hp * Wc);
+        }
+    };
 
     // per-thread staging rows: row = (tid>>3) + 32*i, chunk column c = tid&7
     const int cc0 = tid & 7;
     int rn[PA], rh[PA], rw[PA];                              // image, and the row's h/w anchor
-    bool rborder[PA];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
         int m = m0 + (tid >> 3) + 32 * i;
-        rborder[i] = false;
         if (m < M) {
-            int n = m / (Hc * Wc), rem = m - n * (Hc * Wc);
-            int hp = rem / Wc, wp = rem - hp * Wc;
+            int n, h, w;
+            decode(m, n, h, w);
             rn[i] = n;
-            if (MODE == MODE_FWD) { rh[i] = hp * a.stride - a.pad_t; rw[i] = wp * a.stride - a.pad_l; }
-            else {
-                int h = hbase + st * hp, w = wbase + st * wp;
-                if (a.reflect) {                             // stride 1: keep destination coords; fold in the gather
-                    rh[i] = h; rw[i] = w;
-                    int p = a.pad_t;
-                    rborder[i] = (h >= 1 && h <= p) || (h >= a.H - 1 - p && h <= a.H - 2) ||
-                                 (w >= 1 && w <= p) || (w >= a.W - 1 - p && w <= a.W - 2);
-                } else { rh[i] = (h + a.pad_t - ph) / st; rw[i] = (w + a.pad_l - pw) / st; }
-            }
+            if (MODE == MODE_FWD) { rh[i] = h * a.stride - a.pad_t; rw[i] = w * a.stride - a.pad_l; }
+            else if (MODE == MODE_DGRAD) { rh[i] = (h + a.pad_t - ph) / st; rw[i] = (w + a.pad_l - pw) / st; }
+            else { rh[i] = h; rw[i] = w; }                   // BORDER keeps destination coords; folds in the gather
         } else rn[i] = -1;
     }
 
@@ -124,8 +147,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     const int ktiles = (nr * ns * cpv + 7) / 8;
 
     u32x4 regP[PA], regQ[QA];
+    bool anyP = false;                                       // BORDER: did this thread load anything for the tile
 
     auto load_tile = [&]() {
+        anyP = false;
         const bool tapok = t_ri < nr;
         const int r = ph + st * t_ri, s = pw + st * t_si;
         // weights
@@ -149,21 +174,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
                     wi = wi < 0 ? -wi : (wi >= a.W ? 2 * (a.W - 1) - wi : wi);
                 } else ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
                 if (ok) regP[i] = ld16(a.src + (((size_t)rn[i] * a.H + hi) * a.W + wi) * SC * ES + t_cc * 16);
-            } else if (!a.reflect) {
+            } else if (MODE == MODE_DGRAD) {
+                // REFLECT convs take this path too (ho = h + p - r): the mirrored contributions of the border
+                // pixels are added by the BORDER launch that follows and overwrites those pixels.
                 int ho = rh[i] - t_ri, wo = rw[i] - t_si;
                 if ((unsigned)ho < (unsigned)a.Ho && (unsigned)wo < (unsigned)a.Wo)
                     regP[i] = ld16(a.src + (((size_t)rn[i] * a.Ho + ho) * a.Wo + wo) * SC * ES + t_cc * 16);
-            } else if (!rborder[i]) {
-                int ho = rh[i] + a.pad_t - r, wo = rw[i] + a.pad_l - s;
-                if ((unsigned)ho < (unsigned)a.Ho && (unsigned)wo < (unsigned)a.Wo)
-                    regP[i] = ld16(a.src + (((size_t)rn[i] * a.Ho + ho) * a.Wo + wo) * SC * ES + t_cc * 16);
-            } else {                                         // MirrorPadGrad fold: sum over reflected preimages
+            } else {                                         // MirrorPadGrad fold: the MIRRORED preimages only
                 int jh[3], jw[3];
                 int nh = reflect_preimages(rh[i], a.H, a.pad_t, jh);
                 int nw = reflect_preimages(rw[i], a.W, a.pad_l, jw);
                 bool first = true;
                 for (int ia = 0; ia < nh; ++ia)
                     for (int ib = 0; ib < nw; ++ib) {
+                        if (ia == 0 && ib == 0) continue;    // the direct term was written by the main launch
                         int ho = jh[ia] - r, wo = jw[ib] - s;
                         if ((unsigned)ho < (unsigned)a.Ho && (unsigned)wo < (unsigned)a.Wo) {
                             u32x4 v = ld16(a.src + (((size_t)rn[i] * a.Ho + ho) * a.Wo + wo) * SC * ES + t_cc * 16);
@@ -171,6 +195,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
                             first = false;
                         }
                     }
+                anyP |= !first;
             }
         }
         // advance the tap iterator by one K-tile (8 chunks)
@@ -198,11 +223,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 
     const int frow = lane & 15, fq = lane >> 4, fsw = frow >> 1;   // fragment row / k-chunk / swizzle key
 
-    if (ktiles > 0) { load_tile(); store_tile(0); }
-    __syncthreads();
-    for (int kt = 0; kt < ktiles; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < ktiles) load_tile();
+    auto compute_tile = [&](int buf) {
         const char* bP = sP + (buf * BM + wm * WM + frow) * 128;
         const char* bQ = sQ + (buf * BN + wn * WN + frow) * 128;
 #pragma unroll
@@ -228,8 +249,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
                     }
                 }
         }
-        if (kt + 1 < ktiles) store_tile(buf ^ 1);
+    };
+
+    if (MODE == MODE_BORDER) {
+        // mirrored terms touch few (tap, pixel) pairs: skip K-tiles in which no row of the block has a source
+        for (int kt = 0; kt < ktiles; ++kt) {
+            load_tile();
+            if (!__syncthreads_or(anyP ? 1 : 0)) continue;   // also fences the previous tile's LDS reads
+            store_tile(0);
+            __syncthreads();
+            compute_tile(0);
+        }
+    } else {
+        if (ktiles > 0) { load_tile(); store_tile(0); }
         __syncthreads();
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < ktiles) load_tile();
+            compute_tile(buf);
+            if (kt + 1 < ktiles) store_tile(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: lane holds D[cout = 4*fq + e][pixel = frow] of each 16x16 tile ----
@@ -240,9 +280,269 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
         size_t dpix;
         if (MODE == MODE_FWD) dpix = (size_t)m;
         else {
-            int n = m / (Hc * Wc), rem = m - n * (Hc * Wc);
-            int hp = rem / Wc, wp = rem - hp * Wc;
-            dpix = ((size_t)n * a.H + hbase + st * hp) * a.W + wbase + st * wp;
+            int n, h, w;
+            decode(m, n, h, w);
+            dpix = ((size_t)n * a.H + h) * a.W + w;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int dc = n0 + wn * WN + i * 16 + fq * 4;
+            if (dc >= DC) continue;
+            float v[4];
+            T* o = reinterpret_cast<T*>(a.dst) + dpix * DC + dc;
+            if (MODE == MODE_BORDER) {                       // add the mirrored terms to what the main launch wrote
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + (float)o[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[i][j][e] + (a.bias ? a.bias[dc + e] : 0.f);
+                    v[e] = act_apply(t, a.act, a.leak);
+                }
+            }
+            if constexpr (sizeof(T) == 2) {
+                bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                *reinterpret_cast<bf16x4*>(o) = pk;
+            } else {
+                *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// v2 GEMM kernel: direct-to-LDS staging (global_load_lds_dwordx4), single 32 KB LDS stage, ~4 blocks per CU.
+//
+// Each wave-instruction writes 1 KiB = 8 tile rows x 128 B linearly (LDS dest = wave-uniform base + lane*16), so the
+// XOR swizzle is applied on the SOURCE side: lane (row, pos) fetches logical chunk pos ^ swz(row) and the fragment
+// reads look chunk j up at position j ^ swz(row) (same involution).  Out-of-range taps / rows read a 16-byte zero
+// page instead of branching.  Two LDS stages: the DMA of tile t+1 is in flight while tile t is multiplied.
+// Tiles up to 256x256 with 8 waves (one block per CU): 128 FLOP per staged byte keeps the L2->LDS stream under
+// what the memory side delivers (PMC: the 128x128 variant was bound there at ~9 TB/s of L2 reads, 93 % hits).
+// -------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) uint32_t g_zero_page[4] = {0u, 0u, 0u, 0u};
+
+template <typename T, int MODE, int BM, int BN, int WGM, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
+    constexpr int VEC = ET<T>::VEC;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int WGN = NW / WGM;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int MI = WM / 16, NI = WN / 16;
+    constexpr int RPP = NW * 8;                 // tile rows staged per pass (one 1-KiB wave-instruction = 8 rows)
+    constexpr int PA = BM / RPP;
+    constexpr int QA = (BN + RPP - 1) / RPP;
+    constexpr int BNR = QA * RPP;               // weight-tile rows incl. padding
+    constexpr int STAGE = (BM + BNR) * 128;     // bytes per LDS stage
+    static_assert(MODE == MODE_FWD || MODE == MODE_DGRAD, "mode");
+    static_assert(BM % RPP == 0 && WM % 16 == 0 && WN % 16 == 0 && WGM * WGN == NW, "tile shape");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages of { P [BM][128], Q [BNR][128] }
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int st = (MODE == MODE_DGRAD) ? a.stride : 1;
+    const int ph = (MODE == MODE_DGRAD) ? (int)blockIdx.z / a.stride : 0;
+    const int pw = (MODE == MODE_DGRAD) ? (int)blockIdx.z % a.stride : 0;
+    const int nr = ph < a.R ? (a.R - ph + st - 1) / st : 0;
+    const int ns = pw < a.S ? (a.S - pw + st - 1) / st : 0;
+    const int SC = (MODE == MODE_FWD) ? a.C : a.K;
+    const int DC = (MODE == MODE_FWD) ? a.K : a.C;
+    const int cpv = SC / VEC;
+    const int wrow = a.R * a.S * SC;
+
+    // ---- pixel space of this block ----
+    int hbase = 0, wbase = 0, Hc, Wc;
+    if (MODE == MODE_FWD) { Hc = a.Ho; Wc = a.Wo; }
+    else {
+        hbase = ((ph - a.pad_t) % st + st) % st;
+        wbase = ((pw - a.pad_l) % st + st) % st;
+        Hc = hbase < a.H ? (a.H - hbase + st - 1) / st : 0;
+        Wc = wbase < a.W ? (a.W - wbase + st - 1) / st : 0;
+    }
+    const int M = a.N * Hc * Wc;
+    const int tilesN = (DC + BN - 1) / BN;
+    // 1-D grid over (M-tile, N-tile) pairs, N fastest, so the N-tiles of one pixel tile run back to back; blocks are
+    // remapped so that each XCD (blocks b, b+8, ... share one) walks a CONTIGUOUS range of pixel tiles: the halo rows
+    // that neighbouring tiles re-read then hit that XCD's private L2 (speed only; any placement is correct).
+    int lid;
+    {
+        const int b = (int)blockIdx.x, nm = (int)gridDim.x;
+        const int q = nm >> 3, rr = nm & 7, xcd = b & 7;
+        lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
+    }
+    const int m0 = (lid / tilesN) * BM, n0 = (lid % tilesN) * BN;
+    if (m0 >= M) return;
+
+    auto decode = [&](int m, int& n, int& h, int& w) {
+        n = m / (Hc * Wc);
+        int rem = m - n * (Hc * Wc);
+        int hp = rem / Wc;
+        h = hbase + st * hp; w = wbase + st * (rem - hp * Wc);
+    };
+
+    // staging rows of this thread: row = (tid>>3) + RPP*i at LDS position (tid&7); logical chunk = pos ^ swz(row)
+    const int lcc = (tid & 7) ^ ((tid >> 4) & 7);             // swz(row) = (row>>1)&7 = (tid>>4)&7 for every i
+    int rn[PA], rh[PA], rw[PA];
+    const bool fold = (MODE == MODE_DGRAD) && a.reflect;     // REFLECT data-gradient: MirrorPadGrad terms on the border
+    unsigned bmask = 0;                                       // rows of this thread that receive mirrored terms
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        int m = m0 + (tid >> 3) + RPP * i;
+        if (m < M) {
+            int n, h, w;
+            decode(m, n, h, w);
+            rn[i] = n;
+            if (fold) {
+                const int p = a.pad_t;
+                bool bd = (h >= 1 && h <= p) || (h >= a.H - 1 - p && h <= a.H - 2) || (w >= 1 && w <= p) || (w >= a.W - 1 - p && w <= a.W - 2);
+                bmask |= bd ? (1u << i) : 0u;
+            }
+            if (MODE == MODE_FWD) { rh[i] = h * a.stride - a.pad_t; rw[i] = w * a.stride - a.pad_l; }
+            else { rh[i] = (h + a.pad_t - ph) / st; rw[i] = (w + a.pad_l - pw) / st; }
+        } else rn[i] = -1;
+    }
+
+    int t_cc, t_ri, t_si;
+    { int ti = lcc / cpv; t_cc = lcc - ti * cpv; t_ri = ns ? ti / ns : nr; t_si = ns ? ti - t_ri * ns : 0; }
+    const int ktiles = (nr * ns * cpv + 7) / 8;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+    u32x4 ex[PA];                                             // mirrored-term sums of this thread's border rows
+    unsigned exmask = 0;
+    auto stage_tile = [&](int stg) {
+        char* sP = smem + stg * STAGE;
+        char* sQ = sP + BM * 128;
+        exmask = 0;
+        const bool tapok = t_ri < nr;
+        const int r = ph + st * t_ri, s = pw + st * t_si;
+        // ---- weights: always direct-to-LDS ----
+#pragma unroll
+        for (int i = 0; i < QA; ++i) {
+            int row = (tid >> 3) + RPP * i, dc = n0 + row;
+            const char* src = zero;
+            if (tapok && dc < DC) src = a.wmat + ((size_t)dc * wrow + (size_t)(r * a.S + s) * SC + t_cc * VEC) * ES;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sQ + (wave * 8 + RPP * i) * 128), 16, 0, 0);
+        }
+        // ---- pixels: direct-to-LDS gather (REFLECT data-gradients take the same path with ho = h + p - r; the
+        //      mirrored MirrorPadGrad terms of border pixels are added to the LDS slot by fixup_tile) ----
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const char* src = zero;
+            if (tapok && rn[i] >= 0) {
+                if (MODE == MODE_FWD) {
+                    int hi = rh[i] + r, wi = rw[i] + s;
+                    bool ok = true;
+                    if (a.reflect) {
+                        hi = hi < 0 ? -hi : (hi >= a.H ? 2 * (a.H - 1) - hi : hi);
+                        wi = wi < 0 ? -wi : (wi >= a.W ? 2 * (a.W - 1) - wi : wi);
+                    } else ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                    if (ok) src = a.src + (((size_t)rn[i] * a.H + hi) * a.W + wi) * SC * ES + t_cc * 16;
+                } else {
+                    int ho = rh[i] - t_ri, wo = rw[i] - t_si;
+                    if ((unsigned)ho < (unsigned)a.Ho && (unsigned)wo < (unsigned)a.Wo)
+                        src = a.src + (((size_t)rn[i] * a.Ho + ho) * a.Wo + wo) * SC * ES + t_cc * 16;
+                }
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sP + (wave * 8 + RPP * i) * 128), 16, 0, 0);
+        }
+        if (fold && bmask && tapok) {
+            // MirrorPadGrad: a border pixel also collects dy from the mirrored preimages of its padded position.
+            // They are summed in registers here and added to the pixel's LDS slot once the DMA has landed.
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                if (!((bmask >> i) & 1u)) continue;
+                int jh[3], jw[3];
+                int nh = reflect_preimages(rh[i] - a.pad_t, a.H, a.pad_t, jh);
+                int nw = reflect_preimages(rw[i] - a.pad_l, a.W, a.pad_l, jw);
+                bool first = true;
+                u32x4 sum = zero16();
+                for (int ia = 0; ia < nh; ++ia)
+                    for (int ib = 0; ib < nw; ++ib) {
+                        if (ia == 0 && ib == 0) continue;
+                        int ho = jh[ia] - r, wo = jw[ib] - s;
+                        if ((unsigned)ho < (unsigned)a.Ho && (unsigned)wo < (unsigned)a.Wo) {
+                            u32x4 t = ld16(a.src + (((size_t)rn[i] * a.Ho + ho) * a.Wo + wo) * SC * ES + t_cc * 16);
+                            sum = first ? t : chunk_add<T>(sum, t);
+                            first = false;
+                        }
+                    }
+                if (!first) { ex[i] = sum; exmask |= 1u << i; }
+            }
+        }
+        t_cc += 8;
+        while (t_cc >= cpv) { t_cc -= cpv; if (++t_si == ns) { t_si = 0; ++t_ri; } }
+    };
+    auto fixup_tile = [&](int stg) {                          // after vmcnt(0): own DMA writes are visible to this wave
+        if (fold && exmask) {
+            char* sP = smem + stg * STAGE;
+#pragma unroll
+            for (int i = 0; i < PA; ++i)
+                if ((exmask >> i) & 1u) {
+                    char* slot = sP + ((tid >> 3) + RPP * i) * 128 + ((tid & 7) << 4);
+                    st16(slot, chunk_add<T>(ld16(slot), ex[i]));
+                }
+        }
+    };
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4, fsw = frow >> 1;
+
+    // 2-stage ring: the loads of tile t+1 are in flight (direct to LDS) while tile t is multiplied; one barrier per tile
+    if (ktiles > 0) stage_tile(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fixup_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < ktiles) stage_tile(cur ^ 1);
+        const char* bP = smem + cur * STAGE + (wm * WM + frow) * 128;
+        const char* bQ = smem + cur * STAGE + BM * 128 + (wn * WN + frow) * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int off = (((fq + 4 * kk) ^ fsw) << 4);
+            u32x4 fw[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) fw[i] = ld16(bQ + i * 16 * 128 + off);
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+                u32x4 fp = ld16(bP + j * 16 * 128 + off);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fw[i]), __builtin_bit_cast(bf16x8, fp), acc[i][j], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                __uint_as_float(fw[i][e]), __uint_as_float(fp[e]), acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + 1 < ktiles) fixup_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+        int m = m0 + wm * WM + j * 16 + frow;
+        if (m >= M) continue;
+        size_t dpix;
+        if (MODE == MODE_FWD) dpix = (size_t)m;
+        else {
+            int n, h, w;
+            decode(m, n, h, w);
+            dpix = ((size_t)n * a.H + h) * a.W + w;
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -511,14 +811,55 @@ static int launch_gemm_cfg(const ConvArgs& a, int64_t Mmax, int DC, int classes,
     return sgg_check_launch();
 }
 
+template <typename T, int MODE, int BM, int BN, int WGM, int NW>
+static int launch_glds_cfg(const ConvArgs& a, int64_t Mmax, int DC, int classes, hipStream_t s) {
+    constexpr int RPP = NW * 8;
+    constexpr size_t lds = 2 * (size_t)(BM + (BN + RPP - 1) / RPP * RPP) * 128;
+    auto kern = conv_gemm_glds_kernel<T, MODE, BM, BN, WGM, NW>;
+    static bool attr_done = false;
+    if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+    const int64_t tilesN = (DC + BN - 1) / BN;
+    int64_t blocks = (Mmax + BM - 1) / BM * tilesN;
+    dim3 grid((unsigned)blocks, 1, (unsigned)classes);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
+    return sgg_check_launch();
+}
+
+// SGG_CONV_IMPL=reg selects the v1 register-staged kernels (kept for A/B runs); default = v2 direct-to-LDS
+static bool use_glds() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SGG_CONV_IMPL"); v = (e && e[0] == 'r') ? 0 : 1; }
+    return v == 1;
+}
+
 template <typename T, int MODE>
 static int launch_gemm(const ConvArgs& a, hipStream_t s) {
     int DC, classes;
     int64_t Mmax;
     if (MODE == MODE_FWD) { DC = a.K; classes = 1; Mmax = (int64_t)a.N * a.Ho * a.Wo; }
-    else {
+    else if (MODE == MODE_BORDER) {
+        DC = a.C; classes = 1;
+        int p2 = 2 * a.pad_t;
+        bool all = a.H <= p2 + 1 || a.W <= p2 + 1;
+        Mmax = (int64_t)a.N * (all ? a.H * a.W : p2 * a.W + (a.H - p2) * p2);
+    } else {
         DC = a.C; classes = a.stride * a.stride;
         Mmax = (int64_t)a.N * ((a.H + a.stride - 1) / a.stride) * ((a.W + a.stride - 1) / a.stride);
+    }
+    if constexpr (MODE != MODE_BORDER) {
+        if (use_glds()) {
+            // big square tiles (8 waves, 1 block per CU) when there is enough work to fill the chip with them
+            if (DC >= 256 && Mmax * ((DC + 255) / 256) >= 256 * 160) return launch_glds_cfg<T, MODE, 256, 256, 2, 8>(a, Mmax, DC, classes, s);
+            if (DC >= 128 && Mmax * ((DC + 127) / 128) >= 256 * 160) return launch_glds_cfg<T, MODE, 256, 128, 4, 8>(a, Mmax, DC, classes, s);
+            if (DC >= 128) return launch_glds_cfg<T, MODE, 128, 128, 2, 4>(a, Mmax, DC, classes, s);
+            if (DC > 16) return launch_glds_cfg<T, MODE, 128, 64, 4, 4>(a, Mmax, DC, classes, s);
+            return launch_glds_cfg<T, MODE, 256, 16, 4, 4>(a, Mmax, DC, classes, s);
+        }
+    }
+    if constexpr (MODE == MODE_BORDER) {               // few pixels, short K loops: small tiles for parallelism
+        if (DC >= 128) return launch_gemm_cfg<T, MODE, 64, 128, 2>(a, Mmax, DC, classes, s);
+        if (DC > 16) return launch_gemm_cfg<T, MODE, 64, 64, 2>(a, Mmax, DC, classes, s);
+        return launch_gemm_cfg<T, MODE, 64, 16, 4>(a, Mmax, DC, classes, s);
     }
     if (DC >= 128) return launch_gemm_cfg<T, MODE, 128, 128, 2>(a, Mmax, DC, classes, s);
     if (DC > 16) return launch_gemm_cfg<T, MODE, 128, 64, 4>(a, Mmax, DC, classes, s);
@@ -575,6 +916,17 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
 
 extern "C" {
 
+// debug aid (not part of include/sggan.h): occupancy the runtime reports for the hot kernels
+int sgg_debug_occupancy(int* out, int cap) {
+    int n = 0, v = 0;
+    if (cap < 4) return SGG_EINVAL;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_gemm_glds_kernel<bf16, MODE_FWD, 256, 256, 2, 8>, 512, 131072); out[n++] = v;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_gemm_glds_kernel<bf16, MODE_DGRAD, 256, 256, 2, 8>, 512, 131072); out[n++] = v;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_gemm_kernel<bf16, MODE_FWD, 128, 128, 2>, 256, 65536); out[n++] = v;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_wgrad_kernel<bf16, 128, 128, 2>, 256, 32768); out[n++] = v;
+    return n;
+}
+
 int sgg_pack_conv_weights(const float* w, int R, int S, int C, int K, int Cpad, int Kpad, int dtype, void* wf, void* wd, void* stream) {
     if (!w || R <= 0 || S <= 0 || C <= 0 || K <= 0 || Cpad < C || Kpad < K || Cpad % SGG_CPAD || Kpad % SGG_CPAD) return SGG_EINVAL;
     int64_t total = (int64_t)R * S * Cpad * Kpad;
@@ -594,7 +946,10 @@ int sgg_conv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w, const f
 int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w, void* dx, void* stream) {
     if (!desc_ok(d) || !dy || !w || !dx) return SGG_EINVAL;
     ConvArgs a = make_args(d, dy, w, nullptr, dx, SGG_ACT_NONE, 0.f);
-    return d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_DGRAD>(a, (hipStream_t)stream) : launch_gemm<float, MODE_DGRAD>(a, (hipStream_t)stream);
+    int rc = d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_DGRAD>(a, (hipStream_t)stream) : launch_gemm<float, MODE_DGRAD>(a, (hipStream_t)stream);
+    if (rc || !a.reflect || use_glds()) return rc;     // v2 folds the mirrored terms inside the main kernel
+    // v1 REFLECT: a second, small launch adds the mirrored (MirrorPadGrad) terms to the border pixels
+    return d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_BORDER>(a, (hipStream_t)stream) : launch_gemm<float, MODE_BORDER>(a, (hipStream_t)stream);
 }
 
 size_t sgg_conv2d_bwd_weight_workspace(const sgg_conv_desc* d) {

@@ -347,8 +347,8 @@ int sgg_seg_class_table(uint32_t* keys_host, uint8_t* vals_host, int capacity) {
 }
 
 int sgg_seg_class_map(const uint8_t* rgb, int channels, int64_t n_pixels, uint8_t* out, void* stream) {
+    if (n_pixels == 0) return SGG_OK;          // empty image: nothing to do (pointers may be null)
     if (!rgb || !out || channels < 3 || n_pixels < 0) return SGG_EINVAL;
-    if (n_pixels == 0) return SGG_OK;
     hipLaunchKernelGGL(seg_class_kernel, dim3(grid_for(n_pixels, 2048)), dim3(256), 0, (hipStream_t)stream, rgb, channels, n_pixels, out);
     return sgg_check_launch();
 }

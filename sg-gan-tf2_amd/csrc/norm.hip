@@ -10,7 +10,7 @@
 
 #define IN_ROWS_PER_CHUNK 256        // pixels per partial-sum chunk
 
-// ws layout: partial[N][chunks][C][2] f32, then sums[N][C][2] f32 (bwd only)
+// ws layout: partial[N][chunks][C][2] f32, then sums[N][C][2] and tot[N][C][2] f32 (bwd only)
 static inline int in_chunks(int64_t HW) { return (int)((HW + IN_ROWS_PER_CHUNK - 1) / IN_ROWS_PER_CHUNK); }
 
 template <typename T, bool BWD>
@@ -75,41 +75,60 @@ __global__ __launch_bounds__(256) void in_partial_kernel(const char* x, const ch
     }
 }
 
-__global__ void in_finalize_fwd_kernel(const float* partial, float* stats, int64_t HW, int C, int chunks, float eps, int NC) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= NC) return;
-    int n = i / C, c = i % C;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < chunks; ++k) {
+// Finalize: one block per (64 channels, image); 4 chunk-lanes per channel, combined in fixed order (deterministic).
+#define FIN_CH 64
+#define FIN_LANES 4
+__device__ inline void fin_reduce(const float* partial, int n, int c, int chunks, int C, int lane, double& s1, double& s2) {
+    s1 = 0.0; s2 = 0.0;
+    for (int k = lane; k < chunks; k += FIN_LANES) {
         size_t o = (((size_t)n * chunks + k) * C + c) * 2;
         s1 += (double)partial[o]; s2 += (double)partial[o + 1];
     }
-    double mean = s1 / (double)HW, var = s2 / (double)HW - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[(size_t)i * 2] = (float)mean;
-    stats[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-// sums[n][c] = (sum g, sum g*xhat) / HW ;  dgamma[c] = sum_n sum g*xhat ; dbeta[c] = sum_n sum g
-__global__ void in_finalize_bwd_kernel(const float* partial, float* sums, float* dgamma, float* dbeta, int64_t HW, int C,
-                                       int chunks, int N, int Cr, int accumulate) {
+__global__ __launch_bounds__(256) void in_finalize_fwd_kernel(const float* partial, float* stats, int64_t HW, int C, int chunks, float eps) {
+    __shared__ double red[FIN_LANES][FIN_CH][2];
+    const int tx = threadIdx.x % FIN_CH, ty = threadIdx.x / FIN_CH;
+    const int c = blockIdx.x * FIN_CH + tx, n = blockIdx.y;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) fin_reduce(partial, n, c, chunks, C, ty, s1, s2);
+    red[ty][tx][0] = s1; red[ty][tx][1] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        for (int l = 1; l < FIN_LANES; ++l) { s1 += red[l][tx][0]; s2 += red[l][tx][1]; }
+        double mean = s1 / (double)HW, var = s2 / (double)HW - mean * mean;
+        if (var < 0.0) var = 0.0;
+        size_t i = (size_t)n * C + c;
+        stats[i * 2] = (float)mean;
+        stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// sums[n][c] = (sum g, sum g*xhat) / HW ; tot[n][c] = the raw sums (for dgamma/dbeta)
+__global__ __launch_bounds__(256) void in_finalize_bwd_kernel(const float* partial, float* sums, float* tot, int64_t HW, int C, int chunks) {
+    __shared__ double red[FIN_LANES][FIN_CH][2];
+    const int tx = threadIdx.x % FIN_CH, ty = threadIdx.x / FIN_CH;
+    const int c = blockIdx.x * FIN_CH + tx, n = blockIdx.y;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) fin_reduce(partial, n, c, chunks, C, ty, s1, s2);
+    red[ty][tx][0] = s1; red[ty][tx][1] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        for (int l = 1; l < FIN_LANES; ++l) { s1 += red[l][tx][0]; s2 += red[l][tx][1]; }
+        size_t i = ((size_t)n * C + c) * 2;
+        sums[i] = (float)(s1 / (double)HW); sums[i + 1] = (float)(s2 / (double)HW);
+        tot[i] = (float)s1; tot[i + 1] = (float)s2;
+    }
+}
+
+// dgamma[c] (+)= sum_n sum g*xhat ; dbeta[c] (+)= sum_n sum g
+__global__ void in_param_grad_kernel(const float* tot, float* dgamma, float* dbeta, int C, int N, int Cr, int accumulate) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    if (c >= Cr) return;
     double tg = 0.0, tb = 0.0;
-    for (int n = 0; n < N; ++n) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < chunks; ++k) {
-            size_t o = (((size_t)n * chunks + k) * C + c) * 2;
-            s1 += (double)partial[o]; s2 += (double)partial[o + 1];
-        }
-        sums[((size_t)n * C + c) * 2] = (float)(s1 / (double)HW);
-        sums[((size_t)n * C + c) * 2 + 1] = (float)(s2 / (double)HW);
-        tb += s1; tg += s2;
-    }
-    if (c < Cr) {
-        dgamma[c] = accumulate ? dgamma[c] + (float)tg : (float)tg;
-        dbeta[c] = accumulate ? dbeta[c] + (float)tb : (float)tb;
-    }
+    for (int n = 0; n < N; ++n) { tb += (double)tot[((size_t)n * C + c) * 2]; tg += (double)tot[((size_t)n * C + c) * 2 + 1]; }
+    dgamma[c] = accumulate ? dgamma[c] + (float)tg : (float)tg;
+    dbeta[c] = accumulate ? dbeta[c] + (float)tb : (float)tb;
 }
 
 template <typename T, bool BWD>
@@ -175,7 +194,7 @@ extern "C" {
 
 size_t sgg_instnorm_workspace(int N, int64_t HW, int C) {
     if (N <= 0 || HW <= 0 || C <= 0) return 0;
-    return ((size_t)N * in_chunks(HW) * C * 2 + (size_t)N * C * 2) * sizeof(float);
+    return ((size_t)N * in_chunks(HW) * C * 2 + (size_t)N * C * 4) * sizeof(float);
 }
 
 int sgg_instnorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* stats,
@@ -190,11 +209,11 @@ int sgg_instnorm_fwd(const void* x, const float* gamma, const float* beta, const
     dim3 gp(chunks, N), ga((unsigned)((HW + rpb - 1) / rpb), N);
     if (dtype == SGG_BF16) {
         hipLaunchKernelGGL((in_partial_kernel<bf16, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, act, leak);
-        hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, partial, stats, HW, C, chunks, eps, N * C);
+        hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, stats, HW, C, chunks, eps);
         hipLaunchKernelGGL((in_apply_kernel<bf16, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak);
     } else if (dtype == SGG_F32) {
         hipLaunchKernelGGL((in_partial_kernel<float, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, act, leak);
-        hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, partial, stats, HW, C, chunks, eps, N * C);
+        hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, stats, HW, C, chunks, eps);
         hipLaunchKernelGGL((in_apply_kernel<float, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak);
     } else return SGG_EINVAL;
     return sgg_check_launch();
@@ -210,15 +229,18 @@ int sgg_instnorm_bwd(const void* dy, const void* x, const float* gamma, const fl
     int chunks = in_chunks(HW);
     float* partial = (float*)ws;
     float* sums = partial + (size_t)N * chunks * C * 2;
+    float* tot = sums + (size_t)N * C * 2;
     int rpb = in_rows_per_block(N, HW, C, 0);
     dim3 gp(chunks, N), ga((unsigned)((HW + rpb - 1) / rpb), N);
     if (dtype == SGG_BF16) {
         hipLaunchKernelGGL((in_partial_kernel<bf16, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, act, leak);
-        hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, sums, dgamma, dbeta, HW, C, chunks, N, C_real, accumulate);
+        hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, sums, tot, HW, C, chunks);
+        hipLaunchKernelGGL(in_param_grad_kernel, dim3((C_real + 255) / 256), dim3(256), 0, s, (const float*)tot, dgamma, dbeta, C, N, C_real, accumulate);
         hipLaunchKernelGGL((in_apply_kernel<bf16, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak);
     } else if (dtype == SGG_F32) {
         hipLaunchKernelGGL((in_partial_kernel<float, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, act, leak);
-        hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, sums, dgamma, dbeta, HW, C, chunks, N, C_real, accumulate);
+        hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, sums, tot, HW, C, chunks);
+        hipLaunchKernelGGL(in_param_grad_kernel, dim3((C_real + 255) / 256), dim3(256), 0, s, (const float*)tot, dgamma, dbeta, C, N, C_real, accumulate);
         hipLaunchKernelGGL((in_apply_kernel<float, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak);
     } else return SGG_EINVAL;
     return sgg_check_launch();

@@ -41,6 +41,15 @@ def _s():
 
 _WS = {}
 
+# Optional timing hook (bench.py): PROFILE(op_name, geom_or_shape) -> object with start()/stop(), or None.
+# Events are recorded on the current stream, i.e. the stream the kernel is launched on.
+PROFILE = None
+
+
+def _prof(name, key):
+    return PROFILE(name, key) if PROFILE is not None else None
+
+
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     """Per-device scratch buffer shared by all launches (single stream => in-order reuse is safe)."""
@@ -119,14 +128,20 @@ def pack_weights(w_hwio: torch.Tensor, Cp: int, Kp: int, dtype, want_fwd=True, w
 def conv_fwd(g: ConvGeom, x, w_fwd, bias, act=A.ACT_NONE, leak=0.0):
     assert tuple(x.shape) == g.x_shape and not g.is_deconv, (tuple(x.shape), g.x_shape)
     y = torch.empty(g.y_shape, dtype=x.dtype, device=x.device)
+    pr = _prof("conv2d_fwd", g)
+    if pr: pr.start()
     A.check(A.lib().sgg_conv2d_fwd(C.byref(g.desc), _p(x), _p(w_fwd), _p(bias), _p(y), act, leak, _s()), "conv2d_fwd")
+    if pr: pr.stop()
     return y
 
 
 def conv_dgrad(g: ConvGeom, dy, w_dgrad):
     assert tuple(dy.shape) == g.y_shape and not g.is_deconv
     dx = torch.empty(g.x_shape, dtype=dy.dtype, device=dy.device)
+    pr = _prof("conv2d_bwd_data", g)
+    if pr: pr.start()
     A.check(A.lib().sgg_conv2d_bwd_data(C.byref(g.desc), _p(dy), _p(w_dgrad), _p(dx), _s()), "conv2d_bwd_data")
+    if pr: pr.stop()
     return dx
 
 
@@ -134,8 +149,11 @@ def conv_wgrad(g: ConvGeom, x, dy, dw, accumulate=False):
     """dw: f32 (R,S,C_real,K_real) view to write / accumulate into."""
     assert tuple(x.shape) == g.x_shape and tuple(dy.shape) == g.y_shape and dw.dtype == torch.float32
     ws = workspace(g.ws_wgrad, x.device)
+    pr = _prof("conv2d_bwd_weight", g)
+    if pr: pr.start()
     A.check(A.lib().sgg_conv2d_bwd_weight(C.byref(g.desc), _p(x), _p(dy), _p(dw), dw.shape[2], dw.shape[3], int(accumulate),
                                           _p(ws), ws.numel(), _s()), "conv2d_bwd_weight")
+    if pr: pr.stop()
 
 
 def deconv_fwd(g: ConvGeom, x, w_dgrad, bias, act=A.ACT_NONE, leak=0.0):
@@ -176,8 +194,11 @@ def instnorm_fwd(x, gamma, beta, residual=None, eps=1e-3, act=A.ACT_NONE, leak=0
     y = torch.empty_like(x)
     stats = torch.empty((N, Cp, 2), dtype=torch.float32, device=x.device)
     ws = workspace(int(A.lib().sgg_instnorm_workspace(N, H * W, Cp)), x.device)
+    pr = _prof("instnorm_fwd", tuple(x.shape))
+    if pr: pr.start()
     A.check(A.lib().sgg_instnorm_fwd(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(stats), N, H * W, Cp, eps, act, leak,
                                      dt(x), _p(ws), ws.numel(), _s()), "instnorm_fwd")
+    if pr: pr.stop()
     return y, stats
 
 

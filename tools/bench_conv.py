@@ -1,0 +1,37 @@
+"""Micro-benchmark of one convolution call site (fwd / dgrad / wgrad) through the C ABI.
+    python tools/bench_conv.py [--n 8 --h 64 --w 128 --c 256 --k 256 --r 3 --stride 1 --pad REFLECT-1 --iters 50 --ops fwd,dgrad,wgrad]
+"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import sggan_amd
+from sggan_amd import kernels as K
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=8); ap.add_argument("--h", type=int, default=64); ap.add_argument("--w", type=int, default=128)
+ap.add_argument("--c", type=int, default=256); ap.add_argument("--k", type=int, default=256); ap.add_argument("--r", type=int, default=3)
+ap.add_argument("--stride", type=int, default=1); ap.add_argument("--pad", default="REFLECT-1")
+ap.add_argument("--iters", type=int, default=50); ap.add_argument("--ops", default="fwd,dgrad,wgrad"); ap.add_argument("--dtype", default="bf16")
+a = ap.parse_args()
+dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+pad, refl = ("VALID", int(a.pad.split("-")[1])) if a.pad.startswith("REFLECT") else (a.pad, 0)
+g = K.conv_geom(a.n, a.h, a.w, a.c, a.k, a.r, a.r, a.stride, pad, refl, dt)
+x = torch.randn(g.x_shape, device="cuda").to(dt)
+dy = torch.randn(g.y_shape, device="cuda").to(dt)
+w = torch.randn((a.r, a.r, a.c, a.k), device="cuda") / (a.r * a.r * a.c) ** 0.5
+wf, wd = K.pack_weights(w, a.c, a.k, dt)
+dw = torch.empty_like(w)
+flops = 2.0 * g.y_shape[0] * g.y_shape[1] * g.y_shape[2] * a.k * a.r * a.r * a.c
+fns = {"fwd": lambda: K.conv_fwd(g, x, wf, None), "dgrad": lambda: K.conv_dgrad(g, dy, wd), "wgrad": lambda: K.conv_wgrad(g, x, dy, dw)}
+for op in a.ops.split(","):
+    f = fns[op]
+    for _ in range(5):
+        f()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(a.iters):
+        f()
+    e.record(); torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / a.iters
+    print(f"{op:6s} {ms*1e3:8.1f} us  {flops/ms/1e9:8.1f} TFLOP/s  ({flops/1e9:.1f} GFLOP)", flush=True)

@@ -74,12 +74,19 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const char* dy, flo
         __syncthreads();
     }
 }
-__global__ void colsum_final_kernel(const float* partial, float* out, int C, int Cr, int chunks, int accumulate) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cr) return;
+// one block per 64 channels; 4 chunk-lanes per channel combined in fixed order
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, float* out, int C, int Cr, int chunks, int accumulate) {
+    __shared__ double red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     double s = 0.0;
-    for (int k = 0; k < chunks; ++k) s += (double)partial[(size_t)k * C + c];
-    out[c] = accumulate ? out[c] + (float)s : (float)s;
+    if (c < C) for (int k = ty; k < chunks; k += 4) s += (double)partial[(size_t)k * C + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < Cr) {
+        s = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+        out[c] = accumulate ? out[c] + (float)s : (float)s;
+    }
 }
 
 // ---------------------------------------------------------------- semantic mask multiply-reduce
@@ -278,7 +285,7 @@ int sgg_bias_grad(const void* dy, float* db, int64_t P, int C, int C_real, int a
     if (dtype == SGG_BF16) hipLaunchKernelGGL(colsum_partial_kernel<bf16>, dim3(chunks), dim3(256), 0, s, (const char*)dy, (float*)ws, P, C);
     else if (dtype == SGG_F32) hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(chunks), dim3(256), 0, s, (const char*)dy, (float*)ws, P, C);
     else return SGG_EINVAL;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, db, C, C_real, chunks, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, (const float*)ws, db, C, C_real, chunks, accumulate);
     return sgg_check_launch();
 }
 

@@ -8,7 +8,7 @@
 // Algorithmic bytes: fwd 2 reads + 1 write of the tensor, bwd 4 reads + 1 write.
 #include "common.h"
 
-#define IN_ROWS_PER_CHUNK 256        // pixels per partial-sum chunk
+#define IN_ROWS_PER_CHUNK 64         // pixels per partial-sum chunk
 
 // ws layout: partial[N][chunks][C][2] f32, then sums[N][C][2] and tot[N][C][2] f32 (bwd only)
 static inline int in_chunks(int64_t HW) { return (int)((HW + IN_ROWS_PER_CHUNK - 1) / IN_ROWS_PER_CHUNK); }

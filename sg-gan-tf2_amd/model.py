@@ -62,26 +62,23 @@ class sggan(object):
         self.real_A = self.seg_A = self.mask_A = self.fake_A = None
         self._loss = torch.zeros(2, dtype=torch.float32, device=self.device)    # [gen_loss, disc_loss] on device
         self.gen_loss, self.disc_loss = self._loss[0:1], self._loss[1:2]
-        self._pg = None
+        self._dp = None
         self._world = 1
 
     # ------------------------------------------------------------------ data parallel (new capability)
     def enable_data_parallel(self, process_group=None):
         """Average gradients over ranks with one all-reduce per network, launched as soon as that
-        network's backward has been queued so it overlaps with the rest of the step."""
-        import torch.distributed as dist
-        self._pg = process_group if process_group is not None else dist.group.WORLD
-        self._world = dist.get_world_size(self._pg)
+        network's backward has been queued so it overlaps with the rest of the step (dp.GradExchange)."""
+        from .dp import GradExchange
+        self._dp = GradExchange(process_group)
+        self._world = self._dp.world
         for net in (self.generator, self.discriminator):       # identical replicas: broadcast rank 0's parameters
-            dist.broadcast(net.P.flat, src=dist.get_global_rank(self._pg, 0) if hasattr(dist, "get_global_rank") else 0, group=self._pg)
+            self._dp.broadcast_(net.P.flat)
             net.P.version += 1
         return self
 
     def _allreduce(self, net):
-        if self._pg is None:
-            return None
-        import torch.distributed as dist
-        return dist.all_reduce(net.P.grad, op=dist.ReduceOp.SUM, group=self._pg, async_op=True)
+        return None if self._dp is None else self._dp.allreduce_async(net.P.grad)
 
     # ------------------------------------------------------------------ the hot path
     def _prep(self, x):

@@ -68,8 +68,11 @@ int sgg_pack_conv_weights(const float* w_hwio, int R, int S, int C, int K, int C
  * fwd: y = act(conv(x) + bias);  bias may be NULL; bias has Kpad f32 entries. */
 int sgg_conv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
                    void* y, int act, float leak, void* stream);
-/* bwd_data: dx = conv^T(dy) including the MirrorPadGrad fold for REFLECT (gen_tape.gradient, model.py:196). */
-int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, void* stream);
+/* bwd_data: dx = conv^T(dy) including the MirrorPadGrad fold for REFLECT (gen_tape.gradient, model.py:196).
+ * ws: sgg_conv2d_bwd_data_workspace() bytes (non-zero only for REFLECT: pre-folded gather rows of the border pixels). */
+size_t sgg_conv2d_bwd_data_workspace(const sgg_conv_desc* d);
+int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
+                        void* ws, size_t ws_bytes, void* stream);
 /* bwd_weight: dw_hwio[R][S][C_real][K_real] f32, overwritten (accumulate=0) or added to (accumulate=1: a network
  * applied twice in one step, model.py:186-187).  ws: sgg_conv2d_bwd_weight_workspace() bytes. */
 size_t sgg_conv2d_bwd_weight_workspace(const sgg_conv_desc* d);

@@ -30,6 +30,7 @@ struct ConvArgs {
     const char* wmat;    // FWD: [K][R*S*C]     DGRAD: [C][R*S*K]
     const float* bias;   // per destination channel or nullptr
     char* dst;           // FWD: y (N,Ho,Wo,K)  DGRAD: dx (N,H,W,C)
+    const char* fold;    // REFLECT DGRAD (v2): pre-folded gather rows of the border pixels [pixel][tap][K], else nullptr
     int N, H, W, C, K, R, S, stride, pad_t, pad_l, Ho, Wo, reflect;
     int act;
     float leak;
@@ -394,9 +395,27 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
             decode(m, n, h, w);
             rn[i] = n;
             if (fold) {
-                const int p = a.pad_t;
-                bool bd = (h >= 1 && h <= p) || (h >= a.H - 1 - p && h <= a.H - 2) || (w >= 1 && w <= p) || (w >= a.W - 1 - p && w <= a.W - 2);
-                bmask |= bd ? (1u << i) : 0u;
+                // border pixel -> its row in the pre-folded side tensor (same enumeration as fold_gather_kernel)
+                const int p = a.pad_t, p2 = 2 * p;
+                const bool all = a.H <= p2 + 1 || a.W <= p2 + 1;
+                const bool rowband = (h >= 1 && h <= p) || (h >= a.H - 1 - p && h <= a.H - 2);
+                const bool colband = (w >= 1 && w <= p) || (w >= a.W - 1 - p && w <= a.W - 2);
+                if (all || rowband || colband) {
+                    int q, Bimg;
+                    if (all) { Bimg = a.H * a.W; q = h * a.W + w; }
+                    else {
+                        Bimg = p2 * a.W + (a.H - p2) * p2;
+                        if (rowband) q = (h <= p ? h - 1 : p + h - (a.H - 1 - p)) * a.W + w;
+                        else {
+                            int hh = h == 0 ? 0 : (h == a.H - 1 ? a.H - p2 - 1 : h - p);
+                            int wi = w <= p ? w - 1 : p + w - (a.W - 1 - p);
+                            q = p2 * a.W + hh * p2 + wi;
+                        }
+                    }
+                    bmask |= 1u << i;
+                    rh[i] = n * Bimg + q; rw[i] = 0;
+                    continue;
+                }
             }
             if (MODE == MODE_FWD) { rh[i] = h * a.stride - a.pad_t; rw[i] = w * a.stride - a.pad_l; }
             else { rh[i] = (h + a.pad_t - ph) / st; rw[i] = (w + a.pad_l - pw) / st; }
@@ -408,12 +427,9 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
     const int ktiles = (nr * ns * cpv + 7) / 8;
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
-    u32x4 ex[PA];                                             // mirrored-term sums of this thread's border rows
-    unsigned exmask = 0;
     auto stage_tile = [&](int stg) {
         char* sP = smem + stg * STAGE;
         char* sQ = sP + BM * 128;
-        exmask = 0;
         const bool tapok = t_ri < nr;
         const int r = ph + st * t_ri, s = pw + st * t_si;
         // ---- weights: always direct-to-LDS ----
@@ -425,8 +441,7 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(sQ + (wave * 8 + RPP * i) * 128), 16, 0, 0);
         }
-        // ---- pixels: direct-to-LDS gather (REFLECT data-gradients take the same path with ho = h + p - r; the
-        //      mirrored MirrorPadGrad terms of border pixels are added to the LDS slot by fixup_tile) ----
+        // ---- pixels: direct-to-LDS gather ----
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const char* src = zero;
@@ -439,6 +454,10 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
                         wi = wi < 0 ? -wi : (wi >= a.W ? 2 * (a.W - 1) - wi : wi);
                     } else ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
                     if (ok) src = a.src + (((size_t)rn[i] * a.H + hi) * a.W + wi) * SC * ES + t_cc * 16;
+                } else if (fold && ((bmask >> i) & 1u)) {
+                    // MirrorPadGrad: border pixels gather from the side tensor, whose row (pixel, tap) already
+                    // holds the sum over the mirrored preimages (fold_gather_kernel)
+                    src = a.fold + ((size_t)rh[i] * (a.R * a.S) + (r * a.S + s)) * SC * ES + t_cc * 16;
                 } else {
                     int ho = rh[i] - t_ri, wo = rw[i] - t_si;
                     if ((unsigned)ho < (unsigned)a.Ho && (unsigned)wo < (unsigned)a.Wo)
@@ -448,45 +467,9 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(sP + (wave * 8 + RPP * i) * 128), 16, 0, 0);
         }
-        if (fold && bmask && tapok) {
-            // MirrorPadGrad: a border pixel also collects dy from the mirrored preimages of its padded position.
-            // They are summed in registers here and added to the pixel's LDS slot once the DMA has landed.
-#pragma unroll
-            for (int i = 0; i < PA; ++i) {
-                if (!((bmask >> i) & 1u)) continue;
-                int jh[3], jw[3];
-                int nh = reflect_preimages(rh[i] - a.pad_t, a.H, a.pad_t, jh);
-                int nw = reflect_preimages(rw[i] - a.pad_l, a.W, a.pad_l, jw);
-                bool first = true;
-                u32x4 sum = zero16();
-                for (int ia = 0; ia < nh; ++ia)
-                    for (int ib = 0; ib < nw; ++ib) {
-                        if (ia == 0 && ib == 0) continue;
-                        int ho = jh[ia] - r, wo = jw[ib] - s;
-                        if ((unsigned)ho < (unsigned)a.Ho && (unsigned)wo < (unsigned)a.Wo) {
-                            u32x4 t = ld16(a.src + (((size_t)rn[i] * a.Ho + ho) * a.Wo + wo) * SC * ES + t_cc * 16);
-                            sum = first ? t : chunk_add<T>(sum, t);
-                            first = false;
-                        }
-                    }
-                if (!first) { ex[i] = sum; exmask |= 1u << i; }
-            }
-        }
         t_cc += 8;
         while (t_cc >= cpv) { t_cc -= cpv; if (++t_si == ns) { t_si = 0; ++t_ri; } }
     };
-    auto fixup_tile = [&](int stg) {                          // after vmcnt(0): own DMA writes are visible to this wave
-        if (fold && exmask) {
-            char* sP = smem + stg * STAGE;
-#pragma unroll
-            for (int i = 0; i < PA; ++i)
-                if ((exmask >> i) & 1u) {
-                    char* slot = sP + ((tid >> 3) + RPP * i) * 128 + ((tid & 7) << 4);
-                    st16(slot, chunk_add<T>(ld16(slot), ex[i]));
-                }
-        }
-    };
-
     f32x4 acc[NI][MI];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -498,7 +481,6 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
     // 2-stage ring: the loads of tile t+1 are in flight (direct to LDS) while tile t is multiplied; one barrier per tile
     if (ktiles > 0) stage_tile(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    fixup_tile(0);
     __syncthreads();
     for (int kt = 0; kt < ktiles; ++kt) {
         const int cur = kt & 1;
@@ -529,7 +511,6 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (kt + 1 < ktiles) fixup_tile(cur ^ 1);
         __syncthreads();
     }
 
@@ -562,6 +543,56 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
                 *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
             }
         }
+    }
+}
+
+// Side tensor for the REFLECT data-gradient: for every border pixel (the pixels MirrorPadGrad adds mirrored terms
+// to) and every tap, the gather row the GEMM needs = sum of dy over all preimages of the pixel's padded position.
+// fold[b][tap][k], b enumerating border pixels per image: the 2p border ROW bands first (all columns), then the
+// 2p border COLUMNS of the remaining rows (or every pixel when the bands overlap).
+__host__ __device__ inline int fold_border_per_image(int H, int W, int p) {
+    int p2 = 2 * p;
+    return (H <= p2 + 1 || W <= p2 + 1) ? H * W : p2 * W + (H - p2) * p2;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fold_gather_kernel(const char* dy, char* fold, int N, int H, int W, int K, int R, int S, int p, int Ho, int Wo) {
+    constexpr int VEC = ET<T>::VEC;
+    const int cpv = K / VEC, taps = R * S, p2 = 2 * p;
+    const bool all = H <= p2 + 1 || W <= p2 + 1;
+    const int Bimg = fold_border_per_image(H, W, p);
+    const int64_t total = (int64_t)N * Bimg * taps * cpv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int ch = (int)(i % cpv);
+        int64_t t = i / cpv;
+        int tap = (int)(t % taps);
+        int b = (int)(t / taps);
+        int n = b / Bimg, q = b - n * Bimg, h, w;
+        if (all) { h = q / W; w = q - h * W; }
+        else if (q < p2 * W) { int hi = q / W; w = q - hi * W; h = hi < p ? 1 + hi : H - 1 - p + (hi - p); }
+        else {
+            q -= p2 * W;
+            int hh = q / p2, wi = q - hh * p2;
+            h = hh == 0 ? 0 : (hh == H - p2 - 1 ? H - 1 : p + hh);
+            w = wi < p ? 1 + wi : W - 1 - p + (wi - p);
+        }
+        int r = tap / S, s = tap - r * S;
+        int jh[3], jw[3];
+        int nh = reflect_preimages(h, H, p, jh), nw = reflect_preimages(w, W, p, jw);
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+        for (int ia = 0; ia < nh; ++ia)
+            for (int ib = 0; ib < nw; ++ib) {
+                int ho = jh[ia] - r, wo = jw[ib] - s;
+                if ((unsigned)ho < (unsigned)Ho && (unsigned)wo < (unsigned)Wo) {
+                    float v[VEC];
+                    ET<T>::unpack(ld16(dy + ((((size_t)n * Ho + ho) * Wo + wo) * K + (size_t)ch * VEC) * sizeof(T)), v);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[e] += v[e];
+                }
+            }
+        st16(fold + (size_t)i * 16, ET<T>::pack(acc));
     }
 }
 
@@ -743,6 +774,167 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         }
 }
 
+// -------------------------------------------------------------------------------------------------
+// v2 weight gradient: 256 (tap,c rows) x 256 (couts) tiles, 8 waves, direct-to-LDS double-buffered staging.
+// Same maths as conv_wgrad_kernel; the pixel-major tiles land in LDS by DMA (1 KiB per wave-instruction = whole
+// tile rows), the XOR swizzle that makes the transposing reads conflict-free is applied on the source side.
+// -------------------------------------------------------------------------------------------------
+template <typename T> __device__ inline int wg2_key(int row) {
+    if constexpr (sizeof(T) == 2) return ((row & 3) | (((row >> 3) & 1) << 2)) << 1;
+    else return (row & 3) << 1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void conv_wgrad_glds_kernel(WgradArgs a) {
+    constexpr int VEC = ET<T>::VEC;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int BT = 256;                               // tile rows (tap,c) and columns (couts)
+    constexpr int BKP = sizeof(T) == 2 ? 64 : 32;         // pixels per stage
+    constexpr int PITCH = BT * ES;                        // tile row pitch in bytes (512 / 1024)
+    constexpr int NCH = PITCH / 16;                       // 16-byte chunks per tile row (32 / 64)
+    constexpr int RPS = 512 / NCH;                        // tile rows staged per pass (16 / 8)
+    constexpr int NP = BKP / RPS;                         // passes per tile (4)
+    constexpr int TILE = BKP * PITCH;                     // bytes per operand tile (32 KB)
+    constexpr int STAGE = 2 * TILE;
+    constexpr int MI = 8, NI = 4;                         // wave tile 128 (rows) x 64 (couts); waves 2 x 4
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages of { X [BKP][PITCH], DY [BKP][PITCH] }
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int Mrows = a.R * a.S * a.C;
+    const int m0 = blockIdx.x * BT, n0 = blockIdx.y * BT;
+    const int pbeg = blockIdx.z * a.pix_per_split;
+    const int pend = min(a.P, pbeg + a.pix_per_split);
+
+    // this thread stages LDS position `pos` of rows prow0 + RPS*i; it holds logical chunk pos ^ key(row)
+    const int pos = tid % NCH, prow0 = tid / NCH;
+    const int lc = pos ^ (wg2_key<T>(prow0) & (NCH - 1));            // key(row) is the same for every pass (see wg2_key)
+    const int mrow = m0 + lc * VEC;
+    const bool xcol_ok = mrow < Mrows;
+    const int tap = xcol_ok ? mrow / a.C : 0, c0 = mrow - tap * a.C;
+    const int tr = tap / a.S, ts = tap - tr * a.S;
+    const bool dcol_ok = (n0 + lc * VEC) < a.K;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+    auto stage_tile = [&](int stg, int p0) {
+        char* sX = smem + stg * STAGE;
+        char* sD = sX + TILE;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int prow = prow0 + RPS * i, p = p0 + prow;
+            const char* sx = zero;
+            const char* sd = zero;
+            if (p < pend) {
+                if (xcol_ok) {
+                    uint32_t n = fdiv((uint32_t)p, a.dHW), rem = (uint32_t)p - n * a.dHW.d;
+                    uint32_t ho = fdiv(rem, a.dW), wo = rem - ho * a.dW.d;
+                    int hi = (int)ho * a.stride - a.pad_t + tr, wi = (int)wo * a.stride - a.pad_l + ts;
+                    bool ok = true;
+                    if (a.reflect) {
+                        hi = hi < 0 ? -hi : (hi >= a.H ? 2 * (a.H - 1) - hi : hi);
+                        wi = wi < 0 ? -wi : (wi >= a.W ? 2 * (a.W - 1) - wi : wi);
+                    } else ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                    if (ok) sx = a.x + ((((size_t)n * a.H + hi) * a.W + wi) * a.C + c0) * ES;
+                }
+                if (dcol_ok) sd = a.dy + ((size_t)p * a.K + n0 + lc * VEC) * ES;
+            }
+            // one wave-instruction = 64 lanes x 16 B = 1 KiB of consecutive tile bytes starting at the wave's first row
+            const int wrow = (wave * 64) / NCH + RPS * i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx,
+                                             (__attribute__((address_space(3))) void*)(sX + wrow * PITCH), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sd,
+                                             (__attribute__((address_space(3))) void*)(sD + wrow * PITCH), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, u = lane & 15;
+    const int ksteps = pend > pbeg ? (pend - pbeg + BKP - 1) / BKP : 0;
+    if (ksteps > 0) stage_tile(0, pbeg);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < ksteps) stage_tile(cur ^ 1, pbeg + (ks + 1) * BKP);
+        const char* bX = smem + cur * STAGE;
+        const char* bD = bX + TILE;
+        if constexpr (sizeof(T) == 2) {
+            const int q = u >> 2, pp = u & 3;
+#pragma unroll
+            for (int k32 = 0; k32 < BKP / 32; ++k32) {
+                const int r0 = k32 * 32 + 8 * g + q, r1 = r0 + 4;
+                const int k0 = wg2_key<T>(r0) & (NCH - 1), k1 = wg2_key<T>(r1) & (NCH - 1);
+                bf16x8 fb[NI];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    int col = wn * 64 + j * 16 + 4 * pp;
+                    int ch = col >> 3, sub = (col & 7) * 2;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(bD + r0 * PITCH + ((ch ^ k0) << 4) + sub));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(bD + r1 * PITCH + ((ch ^ k1) << 4) + sub));
+                    fb[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    int col = wm * 128 + i * 16 + 4 * pp;
+                    int ch = col >> 3, sub = (col & 7) * 2;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(bX + r0 * PITCH + ((ch ^ k0) << 4) + sub));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(bX + r1 * PITCH + ((ch ^ k1) << 4) + sub));
+                    bf16x8 fa = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s4 = 0; s4 < BKP / 4; ++s4) {
+                const int row = 4 * s4 + g;
+                const int key = wg2_key<T>(row) & (NCH - 1);
+                float fb[NI];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    int col = wn * 64 + j * 16 + u;
+                    fb[j] = *reinterpret_cast<const float*>(bD + row * PITCH + (((col >> 2) ^ key) << 4) + (col & 3) * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    int col = wm * 128 + i * 16 + u;
+                    float fa = *reinterpret_cast<const float*>(bX + row * PITCH + (((col >> 2) ^ key) << 4) + (col & 3) * 4);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    float* slab = a.ws + (size_t)blockIdx.z * Mrows * a.K;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            int k = n0 + wn * 64 + j * 16 + u;
+            if (k >= a.K) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int mr = m0 + wm * 128 + i * 16 + g * 4 + e;
+                if (mr < Mrows) slab[(size_t)mr * a.K + k] = acc[i][j][e];
+            }
+        }
+}
+
 // dw[tap][c<Cr][k<Kr] (+)= sum_split ws[split][tap*C + c][k]   (fixed order -> deterministic)
 __global__ void wgrad_reduce_kernel(const float* ws, float* dw, int taps, int C, int K, int Cr, int Kr, int splits, int accumulate) {
     int64_t total = (int64_t)taps * Cr * Kr;
@@ -793,7 +985,7 @@ static bool desc_ok(const sgg_conv_desc* d) {
 
 static ConvArgs make_args(const sgg_conv_desc* d, const void* src, const void* w, const float* bias, void* dst, int act, float leak) {
     ConvArgs a;
-    a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst;
+    a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst; a.fold = nullptr;
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S; a.stride = d->stride;
     a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.reflect = d->pad_mode == SGG_PAD_REFLECT;
     a.act = act; a.leak = leak;
@@ -878,8 +1070,20 @@ static int launch_wgrad_cfg(WgradArgs& a, int splits, hipStream_t s) {
     return sgg_check_launch();
 }
 
+static bool wgrad_use_v2(const sgg_conv_desc* d) {
+    return use_glds() && d->K >= 256 && d->R * d->S * d->C >= 256;
+}
+
 static int wgrad_splits(const sgg_conv_desc* d) {
     int64_t P = (int64_t)d->N * d->Ho * d->Wo;
+    if (wgrad_use_v2(d)) {                                         // one 8-wave block per CU: ~256 blocks in all
+        int64_t tiles = (int64_t)((d->R * d->S * d->C + 255) / 256) * ((d->K + 255) / 256);
+        int64_t sp = 256 / tiles, maxs = (P + 127) / 128;
+        if (sp > maxs) sp = maxs;
+        if (sp < 1) sp = 1;
+        if (sp > 64) sp = 64;
+        return (int)sp;
+    }
     int bnw = d->K >= 128 ? 128 : (d->K > 16 ? 64 : 16);
     int64_t tiles = (int64_t)((d->R * d->S * d->C + 127) / 128) * ((d->K + bnw - 1) / bnw);
     int64_t want = (1024 + tiles - 1) / tiles;                 // ~4 blocks per CU
@@ -898,13 +1102,21 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
     a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.reflect = d->pad_mode == SGG_PAD_REFLECT;
     a.P = d->N * d->Ho * d->Wo;
     int splits = wgrad_splits(d);
-    a.pix_per_split = (int)align_up((size_t)((a.P + splits - 1) / splits), 32);
+    a.pix_per_split = (int)align_up((size_t)((a.P + splits - 1) / splits), 64);
     splits = (a.P + a.pix_per_split - 1) / a.pix_per_split;
     a.dHW = make_fastdiv((uint32_t)(d->Ho * d->Wo)); a.dW = make_fastdiv((uint32_t)d->Wo);
     size_t need = (size_t)splits * d->R * d->S * d->C * d->K * sizeof(float);
     if (ws_bytes < need || !ws) return SGG_EWORKSPACE;
     int rc;
-    if (d->K >= 128) rc = launch_wgrad_cfg<T, 128, 128, 2>(a, splits, s);
+    if (wgrad_use_v2(d)) {
+        constexpr size_t lds = 2 * 2 * (size_t)(sizeof(T) == 2 ? 64 : 32) * 256 * sizeof(T);
+        auto kern = conv_wgrad_glds_kernel<T>;
+        static bool attr_done = false;
+        if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+        dim3 grid((unsigned)((d->R * d->S * d->C + 255) / 256), (unsigned)((d->K + 255) / 256), (unsigned)splits);
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
+        rc = sgg_check_launch();
+    } else if (d->K >= 128) rc = launch_wgrad_cfg<T, 128, 128, 2>(a, splits, s);
     else if (d->K > 16) rc = launch_wgrad_cfg<T, 128, 64, 4>(a, splits, s);
     else rc = launch_wgrad_cfg<T, 128, 16, 4>(a, splits, s);
     if (rc) return rc;
@@ -943,9 +1155,25 @@ int sgg_conv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w, const f
     return d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_FWD>(a, (hipStream_t)stream) : launch_gemm<float, MODE_FWD>(a, (hipStream_t)stream);
 }
 
-int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w, void* dx, void* stream) {
+size_t sgg_conv2d_bwd_data_workspace(const sgg_conv_desc* d) {
+    if (!desc_ok(d) || d->pad_mode != SGG_PAD_REFLECT) return 0;
+    size_t es = d->dtype == SGG_BF16 ? 2 : 4;
+    return (size_t)d->N * fold_border_per_image(d->H, d->W, d->pad_t) * d->R * d->S * d->K * es;
+}
+
+int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w, void* dx, void* ws, size_t ws_bytes, void* stream) {
     if (!desc_ok(d) || !dy || !w || !dx) return SGG_EINVAL;
     ConvArgs a = make_args(d, dy, w, nullptr, dx, SGG_ACT_NONE, 0.f);
+    if (a.reflect && use_glds()) {
+        // v2: pre-fold the gather rows of the border pixels, then ONE GEMM launch reads them like any other source
+        size_t need = sgg_conv2d_bwd_data_workspace(d);
+        if (!ws || ws_bytes < need) return SGG_EWORKSPACE;
+        int64_t total = (int64_t)(need / 16);
+        int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+        if (d->dtype == SGG_BF16) hipLaunchKernelGGL(fold_gather_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char*)dy, (char*)ws, d->N, d->H, d->W, d->K, d->R, d->S, d->pad_t, d->Ho, d->Wo);
+        else hipLaunchKernelGGL(fold_gather_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char*)dy, (char*)ws, d->N, d->H, d->W, d->K, d->R, d->S, d->pad_t, d->Ho, d->Wo);
+        a.fold = (const char*)ws;
+    }
     int rc = d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_DGRAD>(a, (hipStream_t)stream) : launch_gemm<float, MODE_DGRAD>(a, (hipStream_t)stream);
     if (rc || !a.reflect || use_glds()) return rc;     // v2 folds the mirrored terms inside the main kernel
     // v1 REFLECT: a second, small launch adds the mirrored (MirrorPadGrad) terms to the border pixels

@@ -70,11 +70,12 @@ def same_pads(n_in: int, k: int, s: int):
 
 class ConvGeom:
     """Geometry of one Conv2D / Conv2DTranspose call site, resolved to an sgg_conv_desc."""
-    __slots__ = ("desc", "x_shape", "y_shape", "ws_wgrad", "dtype", "is_deconv")
+    __slots__ = ("desc", "x_shape", "y_shape", "ws_wgrad", "ws_dgrad", "dtype", "is_deconv")
 
     def __init__(self, desc, x_shape, y_shape, dtype, is_deconv):
         self.desc, self.x_shape, self.y_shape, self.dtype, self.is_deconv = desc, x_shape, y_shape, dtype, is_deconv
         self.ws_wgrad = int(A.lib().sgg_conv2d_bwd_weight_workspace(C.byref(desc)))
+        self.ws_dgrad = int(A.lib().sgg_conv2d_bwd_data_workspace(C.byref(desc)))
         if self.ws_wgrad == 0:
             raise A.SggError(f"invalid convolution geometry {[(f, getattr(desc, f)) for f, _ in desc._fields_]}")
 
@@ -140,7 +141,8 @@ def conv_dgrad(g: ConvGeom, dy, w_dgrad):
     dx = torch.empty(g.x_shape, dtype=dy.dtype, device=dy.device)
     pr = _prof("conv2d_bwd_data", g)
     if pr: pr.start()
-    A.check(A.lib().sgg_conv2d_bwd_data(C.byref(g.desc), _p(dy), _p(w_dgrad), _p(dx), _s()), "conv2d_bwd_data")
+    ws = workspace(g.ws_dgrad, dy.device) if g.ws_dgrad else None
+    A.check(A.lib().sgg_conv2d_bwd_data(C.byref(g.desc), _p(dy), _p(w_dgrad), _p(dx), _p(ws), g.ws_dgrad, _s()), "conv2d_bwd_data")
     if pr: pr.stop()
     return dx
 

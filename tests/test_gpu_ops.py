@@ -58,6 +58,10 @@ CONV_CASES = [
     ("valid_s1", 3, 1, "VALID", 64, 72, 7, 15),
     ("d_h0", 3, 2, "SAME", 3, 64, 16, 16),
     ("wide_k", 3, 1, "SAME", 256, 136, 6, 6),
+    ("res_full_width", 3, 1, "REFLECT-1", 256, 256, 10, 12),
+    ("d_h3_like", 3, 1, "SAME", 256, 512, 6, 9),
+    ("c3_like_s2", 3, 2, "SAME", 128, 256, 12, 10),
+    ("h31_like", 3, 2, "VALID", 512, 512, 9, 11),
 ]
 
 

@@ -65,11 +65,13 @@ int sgg_pack_conv_weights(const float* w_hwio, int R, int S, int C, int K, int C
                           int dtype, void* w_fwd, void* w_dgrad, void* stream);
 
 /* ---- conv2d: tf.keras.layers.Conv2D (+ tf.pad REFLECT) ---- module.py:210-216,230-232,236,240,262-264,284-311
- * fwd: y = act(conv(x) + bias);  bias may be NULL; bias has Kpad f32 entries. */
+ * fwd: y = act(conv(x) + bias);  bias may be NULL; bias has Kpad f32 entries.
+ * ws: sgg_conv2d_fwd_workspace() bytes (non-zero only for small outputs, which are computed split-K). */
+size_t sgg_conv2d_fwd_workspace(const sgg_conv_desc* d);
 int sgg_conv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
-                   void* y, int act, float leak, void* stream);
+                   void* y, int act, float leak, void* ws, size_t ws_bytes, void* stream);
 /* bwd_data: dx = conv^T(dy) including the MirrorPadGrad fold for REFLECT (gen_tape.gradient, model.py:196).
- * ws: sgg_conv2d_bwd_data_workspace() bytes (non-zero only for REFLECT: pre-folded gather rows of the border pixels). */
+ * ws: sgg_conv2d_bwd_data_workspace() bytes (REFLECT: pre-folded gather rows of the border pixels; small outputs: split-K slabs). */
 size_t sgg_conv2d_bwd_data_workspace(const sgg_conv_desc* d);
 int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
                         void* ws, size_t ws_bytes, void* stream);
@@ -83,9 +85,12 @@ int sgg_conv2d_bwd_weight(const sgg_conv_desc* d, const void* x, const void* dy,
  * `d` describes the EQUIVALENT FORWARD CONV whose input is the deconv OUTPUT:
  *   (d->N,H,W,C) = deconv output, (d->Ho,Wo,K) = deconv input, pad_t/pad_l = TF SAME leading pads of that conv.
  * fwd: y[N,H,W,C] = act(conv^T(x[N,Ho,Wo,K]) + bias[C]). */
+size_t sgg_deconv2d_fwd_workspace(const sgg_conv_desc* d);
 int sgg_deconv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w_dgrad, const float* bias,
-                     void* y, int act, float leak, void* stream);
-int sgg_deconv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w_fwd, void* dx, void* stream);
+                     void* y, int act, float leak, void* ws, size_t ws_bytes, void* stream);
+size_t sgg_deconv2d_bwd_data_workspace(const sgg_conv_desc* d);
+int sgg_deconv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w_fwd, void* dx,
+                          void* ws, size_t ws_bytes, void* stream);
 /* dw has the Keras transpose-kernel layout [R][S][C_real(out)][K_real(in)]. */
 int sgg_deconv2d_bwd_weight(const sgg_conv_desc* d, const void* x, const void* dy, float* dw,
                             int C_real, int K_real, int accumulate, void* ws, size_t ws_bytes, void* stream);

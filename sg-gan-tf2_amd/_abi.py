@@ -32,13 +32,16 @@ SIGNATURES = {
     "sgg_version": (_i, []),
     "sgg_strerror": (C.c_char_p, [_i]),
     "sgg_pack_conv_weights": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "sgg_conv2d_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _i, _f, _vp]),
+    "sgg_conv2d_fwd_workspace": (_sz, [_dp]),
+    "sgg_conv2d_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _i, _f, _vp, _sz, _vp]),
     "sgg_conv2d_bwd_data_workspace": (_sz, [_dp]),
     "sgg_conv2d_bwd_data": (_i, [_dp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgg_conv2d_bwd_weight_workspace": (_sz, [_dp]),
     "sgg_conv2d_bwd_weight": (_i, [_dp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
-    "sgg_deconv2d_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _i, _f, _vp]),
-    "sgg_deconv2d_bwd_data": (_i, [_dp, _vp, _vp, _vp, _vp]),
+    "sgg_deconv2d_fwd_workspace": (_sz, [_dp]),
+    "sgg_deconv2d_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _i, _f, _vp, _sz, _vp]),
+    "sgg_deconv2d_bwd_data_workspace": (_sz, [_dp]),
+    "sgg_deconv2d_bwd_data": (_i, [_dp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgg_deconv2d_bwd_weight": (_i, [_dp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sgg_bias_grad_workspace": (_sz, [_i64, _i]),
     "sgg_bias_grad": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -31,6 +31,9 @@ struct ConvArgs {
     const float* bias;   // per destination channel or nullptr
     char* dst;           // FWD: y (N,Ho,Wo,K)  DGRAD: dx (N,H,W,C)
     const char* fold;    // REFLECT DGRAD (v2): pre-folded gather rows of the border pixels [pixel][tap][K], else nullptr
+    float* partial;      // split-K (v2): f32 slabs [ksplit][pdst][DC]
+    int ksplit;          // 1 = no split
+    size_t pdst;         // destination pixels (slab stride)
     int N, H, W, C, K, R, S, stride, pad_t, pad_l, Ho, Wo, reflect;
     int act;
     float leak;
@@ -422,9 +425,13 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
         } else rn[i] = -1;
     }
 
+    // split-K (a.ksplit > 1): blockIdx.y selects a contiguous range of K-tiles; partial sums go to f32 slabs
+    const int ktot = (nr * ns * cpv + 7) / 8;
+    const int kper = (ktot + a.ksplit - 1) / a.ksplit;
+    const int kt0 = (int)blockIdx.y * kper;
+    const int ktiles = max(0, min(ktot, kt0 + kper) - kt0);
     int t_cc, t_ri, t_si;
-    { int ti = lcc / cpv; t_cc = lcc - ti * cpv; t_ri = ns ? ti / ns : nr; t_si = ns ? ti - t_ri * ns : 0; }
-    const int ktiles = (nr * ns * cpv + 7) / 8;
+    { int q0 = lcc + kt0 * 8; int ti = q0 / cpv; t_cc = q0 - ti * cpv; t_ri = ns ? ti / ns : nr; t_si = ns ? ti - t_ri * ns : 0; }
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
     auto stage_tile = [&](int stg) {
@@ -529,6 +536,11 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
         for (int i = 0; i < NI; ++i) {
             int dc = n0 + wn * WN + i * 16 + fq * 4;
             if (dc >= DC) continue;
+            if (a.ksplit > 1) {                                  // f32 partial; bias/activation are applied by the reducer
+                float* o = a.partial + ((size_t)blockIdx.y * a.pdst + dpix) * DC + dc;
+                *reinterpret_cast<f32x4*>(o) = acc[i][j];
+                continue;
+            }
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -985,7 +997,7 @@ static bool desc_ok(const sgg_conv_desc* d) {
 
 static ConvArgs make_args(const sgg_conv_desc* d, const void* src, const void* w, const float* bias, void* dst, int act, float leak) {
     ConvArgs a;
-    a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst; a.fold = nullptr;
+    a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst; a.fold = nullptr; a.partial = nullptr; a.ksplit = 1; a.pdst = 0;
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S; a.stride = d->stride;
     a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.reflect = d->pad_mode == SGG_PAD_REFLECT;
     a.act = act; a.leak = leak;
@@ -1003,6 +1015,35 @@ static int launch_gemm_cfg(const ConvArgs& a, int64_t Mmax, int DC, int classes,
     return sgg_check_launch();
 }
 
+// out[p][c] = act(sum_s partial[s][p][c] + bias[c])  (fixed order -> deterministic)
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial, const float* bias, char* out, int64_t nvec4, int DC,
+                                                            int ksplit, size_t slab, int act, float leak) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 s4 = *reinterpret_cast<const f32x4*>(partial + i * 4);
+        for (int sp = 1; sp < ksplit; ++sp) s4 += *reinterpret_cast<const f32x4*>(partial + sp * slab + i * 4);
+        int c = (int)((i * 4) % DC);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_apply(s4[e] + (bias ? bias[c + e] : 0.f), act, leak);
+        if constexpr (sizeof(T) == 2) {
+            bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *reinterpret_cast<bf16x4*>(out + i * 8) = pk;
+        } else *reinterpret_cast<f32x4*>(out + i * 16) = (f32x4){v[0], v[1], v[2], v[3]};
+    }
+}
+
+// split-K factor for layers whose output is too small to fill the chip (D's tail: 5x13..15x31 maps, K = 4608)
+static int conv_ksplit(int64_t Mmax, int DC, int classes, int ktot_max) {
+    int64_t bm = 128, bn = DC >= 128 ? 128 : (DC > 16 ? 64 : 16);
+    int64_t blocks = ((Mmax + bm - 1) / bm) * ((DC + bn - 1) / bn) * classes;
+    if (blocks >= 96 || ktot_max < 16) return 1;
+    int64_t ks = (256 + blocks - 1) / blocks;
+    if (ks > ktot_max / 4) ks = ktot_max / 4;
+    if (ks > 16) ks = 16;
+    return ks < 2 ? 1 : (int)ks;
+}
+
 template <typename T, int MODE, int BM, int BN, int WGM, int NW>
 static int launch_glds_cfg(const ConvArgs& a, int64_t Mmax, int DC, int classes, hipStream_t s) {
     constexpr int RPP = NW * 8;
@@ -1012,7 +1053,7 @@ static int launch_glds_cfg(const ConvArgs& a, int64_t Mmax, int DC, int classes,
     if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
     const int64_t tilesN = (DC + BN - 1) / BN;
     int64_t blocks = (Mmax + BM - 1) / BM * tilesN;
-    dim3 grid((unsigned)blocks, 1, (unsigned)classes);
+    dim3 grid((unsigned)blocks, (unsigned)a.ksplit, (unsigned)classes);
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
     return sgg_check_launch();
 }
@@ -1056,6 +1097,42 @@ static int launch_gemm(const ConvArgs& a, hipStream_t s) {
     if (DC >= 128) return launch_gemm_cfg<T, MODE, 128, 128, 2>(a, Mmax, DC, classes, s);
     if (DC > 16) return launch_gemm_cfg<T, MODE, 128, 64, 4>(a, Mmax, DC, classes, s);
     return launch_gemm_cfg<T, MODE, 256, 16, 4>(a, Mmax, DC, classes, s);
+}
+
+// split-K planning shared by the workspace queries and the launches
+struct GemmPlan { int DC, classes, ktot_max, ksplit; int64_t Mmax; size_t pdst, ws_bytes; };
+static GemmPlan plan_gemm(const sgg_conv_desc* d, int mode) {
+    GemmPlan g;
+    const int vec = d->dtype == SGG_BF16 ? 8 : 4;
+    if (mode == MODE_FWD) {
+        g.DC = d->K; g.classes = 1; g.Mmax = (int64_t)d->N * d->Ho * d->Wo; g.pdst = (size_t)g.Mmax;
+        g.ktot_max = (d->R * d->S * (d->C / vec) + 7) / 8;
+    } else {
+        const int st = d->stride;
+        g.DC = d->C; g.classes = st * st;
+        g.Mmax = (int64_t)d->N * ((d->H + st - 1) / st) * ((d->W + st - 1) / st);
+        g.pdst = (size_t)d->N * d->H * d->W;
+        g.ktot_max = (((d->R + st - 1) / st) * ((d->S + st - 1) / st) * (d->K / vec) + 7) / 8;
+    }
+    g.ksplit = use_glds() ? conv_ksplit(g.Mmax, g.DC, g.classes, g.ktot_max) : 1;
+    g.ws_bytes = g.ksplit > 1 ? (size_t)g.ksplit * g.pdst * g.DC * sizeof(float) : 0;
+    return g;
+}
+
+template <typename T, int MODE>
+static int run_gemm(const sgg_conv_desc* d, ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
+    GemmPlan g = plan_gemm(d, MODE);
+    if (g.ksplit > 1) {
+        if (!ws || ws_bytes < g.ws_bytes) return SGG_EWORKSPACE;
+        a.ksplit = g.ksplit; a.partial = (float*)ws; a.pdst = g.pdst;
+    }
+    int rc = launch_gemm<T, MODE>(a, s);
+    if (rc || g.ksplit <= 1) return rc;
+    int64_t nvec4 = (int64_t)g.pdst * g.DC / 4;
+    int blocks = (int)((nvec4 + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, s, (const float*)ws, a.bias, a.dst, nvec4, g.DC, g.ksplit,
+                       g.pdst * g.DC, a.act, a.leak);
+    return sgg_check_launch();
 }
 
 template <typename T, int BMW, int BNW, int WGM>
@@ -1149,33 +1226,48 @@ int sgg_pack_conv_weights(const float* w, int R, int S, int C, int K, int Cpad, 
     return sgg_check_launch();
 }
 
-int sgg_conv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act, float leak, void* stream) {
+size_t sgg_conv2d_fwd_workspace(const sgg_conv_desc* d) {
+    return desc_ok(d) ? plan_gemm(d, MODE_FWD).ws_bytes : 0;
+}
+
+int sgg_conv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act, float leak,
+                   void* ws, size_t ws_bytes, void* stream) {
     if (!desc_ok(d) || !x || !w || !y) return SGG_EINVAL;
     ConvArgs a = make_args(d, x, w, bias, y, act, leak);
-    return d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_FWD>(a, (hipStream_t)stream) : launch_gemm<float, MODE_FWD>(a, (hipStream_t)stream);
+    return d->dtype == SGG_BF16 ? run_gemm<bf16, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream)
+                                : run_gemm<float, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream);
+}
+
+static size_t fold_bytes(const sgg_conv_desc* d) {
+    if (d->pad_mode != SGG_PAD_REFLECT || !use_glds()) return 0;
+    size_t es = d->dtype == SGG_BF16 ? 2 : 4;
+    return align_up((size_t)d->N * fold_border_per_image(d->H, d->W, d->pad_t) * d->R * d->S * d->K * es, 256);
 }
 
 size_t sgg_conv2d_bwd_data_workspace(const sgg_conv_desc* d) {
-    if (!desc_ok(d) || d->pad_mode != SGG_PAD_REFLECT) return 0;
-    size_t es = d->dtype == SGG_BF16 ? 2 : 4;
-    return (size_t)d->N * fold_border_per_image(d->H, d->W, d->pad_t) * d->R * d->S * d->K * es;
+    if (!desc_ok(d)) return 0;
+    return fold_bytes(d) + plan_gemm(d, MODE_DGRAD).ws_bytes;
 }
 
 int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w, void* dx, void* ws, size_t ws_bytes, void* stream) {
     if (!desc_ok(d) || !dy || !w || !dx) return SGG_EINVAL;
     ConvArgs a = make_args(d, dy, w, nullptr, dx, SGG_ACT_NONE, 0.f);
-    if (a.reflect && use_glds()) {
+    const size_t fb = fold_bytes(d);
+    if (fb) {
         // v2: pre-fold the gather rows of the border pixels, then ONE GEMM launch reads them like any other source
-        size_t need = sgg_conv2d_bwd_data_workspace(d);
-        if (!ws || ws_bytes < need) return SGG_EWORKSPACE;
-        int64_t total = (int64_t)(need / 16);
+        if (!ws || ws_bytes < fb) return SGG_EWORKSPACE;
+        size_t es = d->dtype == SGG_BF16 ? 2 : 4;
+        int64_t total = (int64_t)d->N * fold_border_per_image(d->H, d->W, d->pad_t) * d->R * d->S * d->K * es / 16;
         int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
         if (d->dtype == SGG_BF16) hipLaunchKernelGGL(fold_gather_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char*)dy, (char*)ws, d->N, d->H, d->W, d->K, d->R, d->S, d->pad_t, d->Ho, d->Wo);
         else hipLaunchKernelGGL(fold_gather_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char*)dy, (char*)ws, d->N, d->H, d->W, d->K, d->R, d->S, d->pad_t, d->Ho, d->Wo);
         a.fold = (const char*)ws;
     }
-    int rc = d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_DGRAD>(a, (hipStream_t)stream) : launch_gemm<float, MODE_DGRAD>(a, (hipStream_t)stream);
-    if (rc || !a.reflect || use_glds()) return rc;     // v2 folds the mirrored terms inside the main kernel
+    void* ws2 = ws ? (char*)ws + fb : nullptr;
+    size_t ws2_bytes = ws_bytes > fb ? ws_bytes - fb : 0;
+    int rc = d->dtype == SGG_BF16 ? run_gemm<bf16, MODE_DGRAD>(d, a, ws2, ws2_bytes, (hipStream_t)stream)
+                                  : run_gemm<float, MODE_DGRAD>(d, a, ws2, ws2_bytes, (hipStream_t)stream);
+    if (rc || !a.reflect || use_glds()) return rc;
     // v1 REFLECT: a second, small launch adds the mirrored (MirrorPadGrad) terms to the border pixels
     return d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_BORDER>(a, (hipStream_t)stream) : launch_gemm<float, MODE_BORDER>(a, (hipStream_t)stream);
 }
@@ -1191,16 +1283,26 @@ int sgg_conv2d_bwd_weight(const sgg_conv_desc* d, const void* x, const void* dy,
                                 : run_wgrad<float>(d, x, dy, dw, Cr, Kr, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
 
-int sgg_deconv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act, float leak, void* stream) {
-    if (!desc_ok(d) || d->pad_mode != SGG_PAD_ZERO || !x || !w || !y) return SGG_EINVAL;
-    ConvArgs a = make_args(d, x, w, bias, y, act, leak);
-    return d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_DGRAD>(a, (hipStream_t)stream) : launch_gemm<float, MODE_DGRAD>(a, (hipStream_t)stream);
+size_t sgg_deconv2d_fwd_workspace(const sgg_conv_desc* d) {
+    return desc_ok(d) ? plan_gemm(d, MODE_DGRAD).ws_bytes : 0;
+}
+size_t sgg_deconv2d_bwd_data_workspace(const sgg_conv_desc* d) {
+    return desc_ok(d) ? plan_gemm(d, MODE_FWD).ws_bytes : 0;
 }
 
-int sgg_deconv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w, void* dx, void* stream) {
+int sgg_deconv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act, float leak,
+                     void* ws, size_t ws_bytes, void* stream) {
+    if (!desc_ok(d) || d->pad_mode != SGG_PAD_ZERO || !x || !w || !y) return SGG_EINVAL;
+    ConvArgs a = make_args(d, x, w, bias, y, act, leak);
+    return d->dtype == SGG_BF16 ? run_gemm<bf16, MODE_DGRAD>(d, a, ws, ws_bytes, (hipStream_t)stream)
+                                : run_gemm<float, MODE_DGRAD>(d, a, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int sgg_deconv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w, void* dx, void* ws, size_t ws_bytes, void* stream) {
     if (!desc_ok(d) || d->pad_mode != SGG_PAD_ZERO || !dy || !w || !dx) return SGG_EINVAL;
     ConvArgs a = make_args(d, dy, w, nullptr, dx, SGG_ACT_NONE, 0.f);
-    return d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_FWD>(a, (hipStream_t)stream) : launch_gemm<float, MODE_FWD>(a, (hipStream_t)stream);
+    return d->dtype == SGG_BF16 ? run_gemm<bf16, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream)
+                                : run_gemm<float, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int sgg_deconv2d_bwd_weight(const sgg_conv_desc* d, const void* x, const void* dy, float* dw, int Cr, int Kr, int accumulate, void* ws, size_t ws_bytes, void* stream) {

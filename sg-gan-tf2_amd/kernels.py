@@ -70,12 +70,15 @@ def same_pads(n_in: int, k: int, s: int):
 
 class ConvGeom:
     """Geometry of one Conv2D / Conv2DTranspose call site, resolved to an sgg_conv_desc."""
-    __slots__ = ("desc", "x_shape", "y_shape", "ws_wgrad", "ws_dgrad", "dtype", "is_deconv")
+    __slots__ = ("desc", "x_shape", "y_shape", "ws_wgrad", "ws_dgrad", "ws_fwd", "dtype", "is_deconv")
 
     def __init__(self, desc, x_shape, y_shape, dtype, is_deconv):
         self.desc, self.x_shape, self.y_shape, self.dtype, self.is_deconv = desc, x_shape, y_shape, dtype, is_deconv
         self.ws_wgrad = int(A.lib().sgg_conv2d_bwd_weight_workspace(C.byref(desc)))
-        self.ws_dgrad = int(A.lib().sgg_conv2d_bwd_data_workspace(C.byref(desc)))
+        L = A.lib()
+        # workspaces of the two GEMM directions; a deconv runs the conv's data-gradient kernel forwards
+        self.ws_fwd = int((L.sgg_deconv2d_fwd_workspace if is_deconv else L.sgg_conv2d_fwd_workspace)(C.byref(desc)))
+        self.ws_dgrad = int((L.sgg_deconv2d_bwd_data_workspace if is_deconv else L.sgg_conv2d_bwd_data_workspace)(C.byref(desc)))
         if self.ws_wgrad == 0:
             raise A.SggError(f"invalid convolution geometry {[(f, getattr(desc, f)) for f, _ in desc._fields_]}")
 
@@ -131,7 +134,8 @@ def conv_fwd(g: ConvGeom, x, w_fwd, bias, act=A.ACT_NONE, leak=0.0):
     y = torch.empty(g.y_shape, dtype=x.dtype, device=x.device)
     pr = _prof("conv2d_fwd", g)
     if pr: pr.start()
-    A.check(A.lib().sgg_conv2d_fwd(C.byref(g.desc), _p(x), _p(w_fwd), _p(bias), _p(y), act, leak, _s()), "conv2d_fwd")
+    ws = workspace(g.ws_fwd, x.device) if g.ws_fwd else None
+    A.check(A.lib().sgg_conv2d_fwd(C.byref(g.desc), _p(x), _p(w_fwd), _p(bias), _p(y), act, leak, _p(ws), g.ws_fwd, _s()), "conv2d_fwd")
     if pr: pr.stop()
     return y
 
@@ -161,14 +165,16 @@ def conv_wgrad(g: ConvGeom, x, dy, dw, accumulate=False):
 def deconv_fwd(g: ConvGeom, x, w_dgrad, bias, act=A.ACT_NONE, leak=0.0):
     assert tuple(x.shape) == g.x_shape and g.is_deconv
     y = torch.empty(g.y_shape, dtype=x.dtype, device=x.device)
-    A.check(A.lib().sgg_deconv2d_fwd(C.byref(g.desc), _p(x), _p(w_dgrad), _p(bias), _p(y), act, leak, _s()), "deconv2d_fwd")
+    ws = workspace(g.ws_fwd, x.device) if g.ws_fwd else None
+    A.check(A.lib().sgg_deconv2d_fwd(C.byref(g.desc), _p(x), _p(w_dgrad), _p(bias), _p(y), act, leak, _p(ws), g.ws_fwd, _s()), "deconv2d_fwd")
     return y
 
 
 def deconv_dgrad(g: ConvGeom, dy, w_fwd):
     assert tuple(dy.shape) == g.y_shape and g.is_deconv
     dx = torch.empty(g.x_shape, dtype=dy.dtype, device=dy.device)
-    A.check(A.lib().sgg_deconv2d_bwd_data(C.byref(g.desc), _p(dy), _p(w_fwd), _p(dx), _s()), "deconv2d_bwd_data")
+    ws = workspace(g.ws_dgrad, dy.device) if g.ws_dgrad else None
+    A.check(A.lib().sgg_deconv2d_bwd_data(C.byref(g.desc), _p(dy), _p(w_fwd), _p(dx), _p(ws), g.ws_dgrad, _s()), "deconv2d_bwd_data")
     return dx
 
 

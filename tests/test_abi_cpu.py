@@ -39,7 +39,9 @@ def test_host_side_validation_without_gpu():
     L = A.lib()
     bad = A.ConvDesc(1, 8, 8, 7, 8, 3, 3, 1, 0, 0, 6, 6, 0, 0)            # C not a multiple of 8
     assert L.sgg_conv2d_bwd_weight_workspace(ctypes.byref(bad)) == 0
-    assert L.sgg_conv2d_fwd(ctypes.byref(bad), None, None, None, None, 0, 0.0, None) == -1
+    assert L.sgg_conv2d_fwd(ctypes.byref(bad), None, None, None, None, 0, 0.0, None, 0, None) == -1
+    tail = A.ConvDesc(8, 7, 15, 512, 512, 3, 3, 1, 0, 0, 5, 13, 0, 1)            # D.h33: tiny output -> split-K slabs
+    assert L.sgg_conv2d_fwd_workspace(ctypes.byref(tail)) > 0
     refl = A.ConvDesc(1, 2, 8, 8, 8, 7, 7, 1, 3, 3, 2, 8, 1, 0)           # REFLECT pad >= size
     assert L.sgg_conv2d_bwd_weight_workspace(ctypes.byref(refl)) == 0
     ok = A.ConvDesc(8, 64, 128, 256, 256, 3, 3, 1, 1, 1, 64, 128, 1, 1)    # the bench's residual conv

@@ -947,17 +947,31 @@ __global__ __launch_bounds__(512) void conv_wgrad_glds_kernel(WgradArgs a) {
         }
 }
 
-// dw[tap][c<Cr][k<Kr] (+)= sum_split ws[split][tap*C + c][k]   (fixed order -> deterministic)
-__global__ void wgrad_reduce_kernel(const float* ws, float* dw, int taps, int C, int K, int Cr, int Kr, int splits, int accumulate) {
-    int64_t total = (int64_t)taps * Cr * Kr;
+// dw[tap][c<Cr][k<Kr] (+)= sum_split ws[split][tap*C + c][k]   (fixed summation tree -> deterministic)
+// One thread per 4 consecutive k (K is a multiple of 8): 16-byte slab reads, 4 independent partial sums in flight.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, float* dw, int taps, int C, int K, int Cr, int Kr, int splits, int accumulate) {
+    const int K4 = K / 4;
+    const int64_t total = (int64_t)taps * Cr * K4;
+    const size_t slab = (size_t)taps * C * K;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int k = (int)(i % Kr);
-        int64_t t = i / Kr;
+        int k4 = (int)(i % K4);
+        int64_t t = i / K4;
         int c = (int)(t % Cr), tap = (int)(t / Cr);
-        size_t off = ((size_t)tap * C + c) * K + k, slab = (size_t)taps * C * K;
-        float s = 0.f;
-        for (int sp = 0; sp < splits; ++sp) s += ws[sp * slab + off];
-        dw[i] = accumulate ? dw[i] + s : s;
+        const float* src = ws + ((size_t)tap * C + c) * K + k4 * 4;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+        int sp = 0;
+        for (; sp + 4 <= splits; sp += 4) {
+            s0 += *reinterpret_cast<const f32x4*>(src + (size_t)sp * slab);
+            s1 += *reinterpret_cast<const f32x4*>(src + (size_t)(sp + 1) * slab);
+            s2 += *reinterpret_cast<const f32x4*>(src + (size_t)(sp + 2) * slab);
+            s3 += *reinterpret_cast<const f32x4*>(src + (size_t)(sp + 3) * slab);
+        }
+        for (; sp < splits; ++sp) s0 += *reinterpret_cast<const f32x4*>(src + (size_t)sp * slab);
+        f32x4 s4 = (s0 + s1) + (s2 + s3);
+        float* o = dw + ((size_t)tap * Cr + c) * Kr + k4 * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (k4 * 4 + e < Kr) o[e] = accumulate ? o[e] + s4[e] : s4[e];
     }
 }
 
@@ -1037,7 +1051,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial
 static int conv_ksplit(int64_t Mmax, int DC, int classes, int ktot_max) {
     int64_t bm = 128, bn = DC >= 128 ? 128 : (DC > 16 ? 64 : 16);
     int64_t blocks = ((Mmax + bm - 1) / bm) * ((DC + bn - 1) / bn) * classes;
-    if (blocks >= 96 || ktot_max < 16) return 1;
+    if (blocks >= 192 || ktot_max < 16) return 1;
     int64_t ks = (256 + blocks - 1) / blocks;
     if (ks > ktot_max / 4) ks = ktot_max / 4;
     if (ks > 16) ks = 16;
@@ -1166,8 +1180,10 @@ static int wgrad_splits(const sgg_conv_desc* d) {
     int64_t want = (1024 + tiles - 1) / tiles;                 // ~4 blocks per CU
     int64_t maxs = (P + 255) / 256;                            // >= 256 pixels per split
     int64_t sp = want < maxs ? want : maxs;
+    int64_t slab = (int64_t)d->R * d->S * d->C * d->K * 4;     // bytes per split
+    int64_t cap = slab <= (1 << 20) ? 256 : 64;                // small slabs: the reduce pass stays cheap
     if (sp < 1) sp = 1;
-    if (sp > 64) sp = 64;
+    if (sp > cap) sp = cap;
     return (int)sp;
 }
 
@@ -1197,8 +1213,8 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
     else if (d->K > 16) rc = launch_wgrad_cfg<T, 128, 64, 4>(a, splits, s);
     else rc = launch_wgrad_cfg<T, 128, 16, 4>(a, splits, s);
     if (rc) return rc;
-    int64_t total = (int64_t)d->R * d->S * Cr * Kr;
-    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    int64_t total = (int64_t)d->R * d->S * Cr * (d->K / 4);
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, dw, d->R * d->S, d->C, d->K, Cr, Kr, splits, accumulate);
     return sgg_check_launch();
 }

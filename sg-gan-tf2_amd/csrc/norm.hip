@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void in_partial_kernel(const char* x, const ch
 }
 
 // Finalize: one block per (64 channels, image); 4 chunk-lanes per channel, combined in fixed order (deterministic).
-#define FIN_CH 64
-#define FIN_LANES 4
+#define FIN_CH 32
+#define FIN_LANES 8
 __device__ inline void fin_reduce(const float* partial, int n, int c, int chunks, int C, int lane, double& s1, double& s2) {
     s1 = 0.0; s2 = 0.0;
     for (int k = lane; k < chunks; k += FIN_LANES) {

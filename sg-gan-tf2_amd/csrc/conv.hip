@@ -558,6 +558,148 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Narrow-output convolution (Cout <= 16, stride 1, same-size output): the generator head, 7x7 64->3 at full
+// resolution (module.py:262-264).  As an implicit GEMM it would re-read every input pixel once per tap (49x) from
+// L2 for a 16-wide output tile; here the block keeps the input HALO of its 16x32-pixel output tile in LDS (one
+// DMA pass, REFLECT/zero padding resolved in the DMA's per-lane source address) and all taps read shifted rows of
+// it.  Weights stream through a small double-buffered LDS ring, one kernel row of taps at a time.
+// -------------------------------------------------------------------------------------------------
+#define HALO_TH 16
+#define HALO_TW 32
+#define HALO_MAXR 7
+
+template <typename T>
+__global__ __launch_bounds__(512) void conv_halo_fwd_kernel(ConvArgs a) {
+    constexpr int VEC = ET<T>::VEC;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int CCH = 128 / ES;                       // channels per halo pass (one 128-byte LDS row per pixel)
+    constexpr int WBUF = HALO_MAXR * 16 * 128;          // one kernel row of taps: [s][16 couts][128 B]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sW = smem;                                    // [2][WBUF]
+    char* sH = smem + 2 * WBUF;                         // halo [(TH+R-1)*(TW+S-1)][128 B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HWd = HALO_TW + a.S - 1, HHd = HALO_TH + a.R - 1, HP = HHd * HWd;
+    const int tilesW = a.W / HALO_TW, tilesH = a.H / HALO_TH;
+    int b = blockIdx.x;
+    const int tw = b % tilesW; b /= tilesW;
+    const int th = b % tilesH;
+    const int n = b / tilesH;
+    const int y0 = th * HALO_TH, x0 = tw * HALO_TW;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    const int wrow = a.R * a.S * a.C;                   // weight row length (elements)
+    const int pos = tid & 7, lsw = (tid >> 4) & 7;      // LDS position / swizzle key of rows (tid>>3) + 64*i
+    const int lcc = pos ^ lsw;                          // logical 16-byte chunk this thread fetches
+
+    auto stage_halo = [&](int cc) {
+        for (int base = 0; base < HP; base += 64) {     // 64 halo pixels (8 per wave-instruction) per pass
+            int hp = base + (tid >> 3);
+            const char* src = zero;
+            if (hp < HP) {
+                int hy = hp / HWd, hx = hp - hy * HWd;
+                int yi = y0 - a.pad_t + hy, xi = x0 - a.pad_l + hx;
+                bool ok = true;
+                if (a.reflect) {
+                    yi = yi < 0 ? -yi : (yi >= a.H ? 2 * (a.H - 1) - yi : yi);
+                    xi = xi < 0 ? -xi : (xi >= a.W ? 2 * (a.W - 1) - xi : xi);
+                } else ok = (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W;
+                if (ok) src = a.src + ((((size_t)n * a.H + yi) * a.W + xi) * a.C + cc * CCH) * ES + lcc * 16;
+            }
+            if (base + wave * 8 < HP + 8)                // wave-uniform: skip instructions wholly past the halo
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(sH + (base + wave * 8) * 128), 16, 0, 0);
+        }
+    };
+    auto stage_weights = [&](int buf, int r, int cc) {   // taps (r, 0..S-1): rows = s*16 + cout
+        for (int base = 0; base < a.S * 16; base += 64) {
+            int row = base + (tid >> 3);
+            const char* src = zero;
+            if (row < a.S * 16) {
+                int s = row >> 4, k = row & 15;
+                if (k < a.K) src = a.wmat + ((size_t)k * wrow + (size_t)(r * a.S + s) * a.C + cc * CCH) * ES + lcc * 16;
+            }
+            if (base + wave * 8 < a.S * 16)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(sW + buf * WBUF + (base + wave * 8) * 128), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+
+    const int nchunks = a.C / CCH;
+    for (int cc = 0; cc < nchunks; ++cc) {
+        __syncthreads();                                 // previous pass has finished reading the halo
+        stage_halo(cc);
+        stage_weights(0, 0, cc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int r = 0; r < a.R; ++r) {
+            const int cur = r & 1;
+            if (r + 1 < a.R) stage_weights(cur ^ 1, r + 1, cc);
+            for (int s = 0; s < a.S; ++s) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int wr = s * 16 + frow;
+                    u32x4 fw = ld16(sW + cur * WBUF + wr * 128 + ((((fq + 4 * kk) ^ ((wr >> 1) & 7))) << 4));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int y = 2 * wave + (j >> 1), x = (j & 1) * 16 + frow;
+                        const int hp = (y + r) * HWd + x + s;
+                        u32x4 fp = ld16(sH + hp * 128 + ((((fq + 4 * kk) ^ ((hp >> 1) & 7))) << 4));
+                        if constexpr (sizeof(T) == 2) {
+                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw), __builtin_bit_cast(bf16x8, fp), acc[j], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fw[e]), __uint_as_float(fp[e]), acc[j], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // D[cout = 4*fq + e][pixel = frow]
+    const int dc = fq * 4;
+    if (dc < a.K) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = y0 + 2 * wave + (j >> 1), x = x0 + (j & 1) * 16 + frow;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[j][e] + (a.bias ? a.bias[dc + e] : 0.f), a.act, a.leak);
+            T* o = reinterpret_cast<T*>(a.dst) + (((size_t)n * a.H + y) * a.W + x) * a.K + dc;
+            if constexpr (sizeof(T) == 2) {
+                bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                *reinterpret_cast<bf16x4*>(o) = pk;
+            } else *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+        }
+    }
+}
+
+static bool halo_fwd_ok(const sgg_conv_desc* d) {
+    const int cch = d->dtype == SGG_BF16 ? 64 : 32;
+    return d->K <= 16 && d->stride == 1 && d->R <= HALO_MAXR && d->S <= HALO_MAXR && d->Ho == d->H && d->Wo == d->W &&
+           d->H % HALO_TH == 0 && d->W % HALO_TW == 0 && d->C % cch == 0;
+}
+
+template <typename T>
+static int launch_halo_fwd(const sgg_conv_desc* d, const ConvArgs& a, hipStream_t s) {
+    size_t lds = 2 * (size_t)HALO_MAXR * 16 * 128 + (size_t)(HALO_TH + d->R - 1) * (HALO_TW + d->S - 1) * 128 + 1024;
+    auto kern = conv_halo_fwd_kernel<T>;
+    static bool attr_done = false;
+    if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    dim3 grid((unsigned)(d->N * (d->H / HALO_TH) * (d->W / HALO_TW)));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
+    return sgg_check_launch();
+}
+
 // Side tensor for the REFLECT data-gradient: for every border pixel (the pixels MirrorPadGrad adds mirrored terms
 // to) and every tap, the gather row the GEMM needs = sum of dy over all preimages of the pixel's padded position.
 // fold[b][tap][k], b enumerating border pixels per image: the 2p border ROW bands first (all columns), then the
@@ -1250,6 +1392,8 @@ int sgg_conv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w, const f
                    void* ws, size_t ws_bytes, void* stream) {
     if (!desc_ok(d) || !x || !w || !y) return SGG_EINVAL;
     ConvArgs a = make_args(d, x, w, bias, y, act, leak);
+    if (use_glds() && halo_fwd_ok(d))                   // narrow output at full resolution: input halo resident in LDS
+        return d->dtype == SGG_BF16 ? launch_halo_fwd<bf16>(d, a, (hipStream_t)stream) : launch_halo_fwd<float>(d, a, (hipStream_t)stream);
     return d->dtype == SGG_BF16 ? run_gemm<bf16, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream)
                                 : run_gemm<float, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream);
 }

@@ -62,6 +62,8 @@ CONV_CASES = [
     ("d_h3_like", 3, 1, "SAME", 256, 512, 6, 9),
     ("c3_like_s2", 3, 2, "SAME", 128, 256, 12, 10),
     ("h31_like", 3, 2, "VALID", 512, 512, 9, 11),
+    ("head_halo_7x7", 7, 1, "REFLECT-3", 64, 3, 32, 64),
+    ("head_halo_3x3_same", 3, 1, "SAME", 128, 10, 16, 32),
 ]
 
 

@@ -39,6 +39,17 @@ struct ConvArgs {
     float leak;
 };
 
+struct WgradArgs {
+    const char* x;       // (N,H,W,C)  gathered operand
+    const char* dy;      // (N,Ho,Wo,K)
+    float* ws;           // [splits][R*S*C][K] f32 slabs
+    int N, H, W, C, K, R, S, stride, pad_t, pad_l, Ho, Wo, reflect;
+    int P, pix_per_split;
+    FastDiv dHW, dW;     // divide by Ho*Wo, Wo
+};
+
+static bool use_glds();
+
 template <typename T>
 __device__ inline u32x4 chunk_add(const u32x4& a, const u32x4& b) {
     float fa[ET<T>::VEC], fb[ET<T>::VEC];
@@ -700,6 +711,146 @@ static int launch_halo_fwd(const sgg_conv_desc* d, const ConvArgs& a, hipStream_
     return sgg_check_launch();
 }
 
+// Weight gradient of the same narrow-output convolution: dW[(r,s,c)][k] = sum_pixels x~[p,(r,s),c] * dy[p][k] with
+// k <= 16, c = 64.  Blocks walk 16x32-pixel tiles persistently; the input halo (DMA) and the dy tile sit in LDS;
+// wave w owns taps w, w+8, ... (<= 7 of the 49) for all 64 channels, accumulating in registers across its tiles;
+// both MFMA operands come from transposing LDS reads (pixels are the reduction index).  One f32 slab per block,
+// summed by wgrad_reduce_kernel.
+template <typename T>
+__global__ __launch_bounds__(512) void conv_halo_wgrad_kernel(WgradArgs a, int ntiles) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int CCH = 128 / ES;                       // channels per halo pass
+    constexpr int CF = CCH / 16;                        // 16-channel fragments per pass (4 bf16 / 2 f32)
+    constexpr int DPITCH = 16 * ES;                     // dy tile: 16 couts per pixel (zero padded)
+    constexpr int TSLOTS = 7;                           // taps per wave (R*S <= 56)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sD = smem;                                    // [512 px][DPITCH]
+    char* sH = smem + 512 * DPITCH;                     // halo
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HWd = HALO_TW + a.S - 1, HHd = HALO_TH + a.R - 1, HP = HHd * HWd;
+    const int tilesW = a.W / HALO_TW, tilesH = a.H / HALO_TH;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    const int pos = tid & 7, lsw = (tid >> 4) & 7, lcc = pos ^ lsw;
+    const int ntaps = a.R * a.S;
+    const int g = lane >> 4, u = lane & 15, q = u >> 2, pp = u & 3;
+
+    f32x4 acc[TSLOTS][4];
+#pragma unroll
+    for (int i = 0; i < TSLOTS; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[i][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int i = tid; i < 512 * DPITCH / 16; i += 512) st16(sD + i * 16, zero16());   // padded couts stay zero
+    const int nchunks = a.C / CCH;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int b = tile;
+        const int tw = b % tilesW; b /= tilesW;
+        const int th = b % tilesH;
+        const int n = b / tilesH;
+        const int y0 = th * HALO_TH, x0 = tw * HALO_TW;
+        for (int cc = 0; cc < nchunks; ++cc) {
+            __syncthreads();
+            for (int base = 0; base < HP; base += 64) {
+                int hp = base + (tid >> 3);
+                const char* src = zero;
+                if (hp < HP) {
+                    int hy = hp / HWd, hx = hp - hy * HWd;
+                    int yi = y0 - a.pad_t + hy, xi = x0 - a.pad_l + hx;
+                    bool ok = true;
+                    if (a.reflect) {
+                        yi = yi < 0 ? -yi : (yi >= a.H ? 2 * (a.H - 1) - yi : yi);
+                        xi = xi < 0 ? -xi : (xi >= a.W ? 2 * (a.W - 1) - xi : xi);
+                    } else ok = (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W;
+                    if (ok) src = a.x + ((((size_t)n * a.H + yi) * a.W + xi) * a.C + cc * CCH) * ES + lcc * 16;
+                }
+                if (base + wave * 8 < HP)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(sH + (base + wave * 8) * 128), 16, 0, 0);
+            }
+            if (cc == 0) {                               // dy tile: thread = pixel; K*ES bytes of real data per pixel
+                const int py = tid >> 5, px = tid & 31;
+                const char* src = a.dy + (((size_t)n * a.H + y0 + py) * a.W + x0 + px) * a.K * ES;
+                for (int o = 0; o < a.K * ES; o += 16) st16(sD + tid * DPITCH + o, ld16(src + o));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int y = 0; y < HALO_TH; ++y) {           // one k-step = the 32 pixels of tile row y
+                if constexpr (sizeof(T) == 2) {
+                    const int p0 = y * 32 + 8 * g + q;
+                    bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(sD + p0 * DPITCH + pp * 8));
+                    bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(sD + (p0 + 4) * DPITCH + pp * 8));
+                    const bf16x8 fb = (bf16x8){blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+#pragma unroll
+                    for (int i = 0; i < TSLOTS; ++i) {
+                        const int t = wave + 8 * i;
+                        if (t >= ntaps) break;
+                        const int r = t / a.S, s = t - r * a.S;
+                        const int h0 = (y + r) * HWd + s + 8 * g + q, h1 = h0 + 4;
+#pragma unroll
+                        for (int c = 0; c < CF; ++c) {
+                            const int col = c * 16 + 4 * pp, ch = col >> 3, sub = (col & 7) * 2;
+                            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                                (__attribute__((address_space(3))) bf16x4*)(sH + h0 * 128 + ((ch ^ ((h0 >> 1) & 7)) << 4) + sub));
+                            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                                (__attribute__((address_space(3))) bf16x4*)(sH + h1 * 128 + ((ch ^ ((h1 >> 1) & 7)) << 4) + sub));
+                            const bf16x8 fa = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[i][c], 0, 0, 0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int s4 = 0; s4 < 8; ++s4) {          // 4 pixels per MFMA
+                        const int xk = 4 * s4 + g;
+                        const float fb = *reinterpret_cast<const float*>(sD + (y * 32 + xk) * DPITCH + u * 4);
+#pragma unroll
+                        for (int i = 0; i < TSLOTS; ++i) {
+                            const int t = wave + 8 * i;
+                            if (t >= ntaps) break;
+                            const int r = t / a.S, s = t - r * a.S;
+                            const int hp = (y + r) * HWd + s + xk;
+#pragma unroll
+                            for (int c = 0; c < CF; ++c) {
+                                const int col = c * 16 + u;
+                                const float fa = *reinterpret_cast<const float*>(sH + hp * 128 + (((col >> 2) ^ ((hp >> 1) & 7)) << 4) + (col & 3) * 4);
+                                acc[i][cc * CF + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, acc[i][cc * CF + c], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // D[row = 4g+e -> channel][col = u -> cout]
+    float* slab = a.ws + (size_t)blockIdx.x * ntaps * a.C * a.K;
+    if (u < a.K) {
+#pragma unroll
+        for (int i = 0; i < TSLOTS; ++i) {
+            const int t = wave + 8 * i;
+            if (t >= ntaps) break;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c * 16 >= a.C) break;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    slab[((size_t)t * a.C + c * 16 + g * 4 + e) * a.K + u] = acc[i][c][e];
+            }
+        }
+    }
+}
+
+static bool halo_wgrad_ok(const sgg_conv_desc* d) {
+    const int cch = d->dtype == SGG_BF16 ? 64 : 32;
+    return use_glds() && d->K <= 16 && d->stride == 1 && d->R <= HALO_MAXR && d->S <= HALO_MAXR && d->R * d->S <= 56 &&
+           d->Ho == d->H && d->Wo == d->W && d->H % HALO_TH == 0 && d->W % HALO_TW == 0 && d->C <= 64 && d->C % cch == 0;
+}
+static int halo_wgrad_blocks(const sgg_conv_desc* d) {
+    int ntiles = d->N * (d->H / HALO_TH) * (d->W / HALO_TW);
+    return ntiles < 256 ? ntiles : 256;
+}
+
 // Side tensor for the REFLECT data-gradient: for every border pixel (the pixels MirrorPadGrad adds mirrored terms
 // to) and every tap, the gather row the GEMM needs = sum of dy over all preimages of the pixel's padded position.
 // fold[b][tap][k], b enumerating border pixels per image: the 2p border ROW bands first (all columns), then the
@@ -753,14 +904,6 @@ __global__ __launch_bounds__(256) void fold_gather_kernel(const char* dy, char* 
 // -------------------------------------------------------------------------------------------------
 // weight gradient
 // -------------------------------------------------------------------------------------------------
-struct WgradArgs {
-    const char* x;       // (N,H,W,C)  gathered operand
-    const char* dy;      // (N,Ho,Wo,K)
-    float* ws;           // [splits][R*S*C][K] f32 slabs
-    int N, H, W, C, K, R, S, stride, pad_t, pad_l, Ho, Wo, reflect;
-    int P, pix_per_split;
-    FastDiv dHW, dW;     // divide by Ho*Wo, Wo
-};
 
 __device__ inline int wg_swz(int chunk, int row, int nchunks) {
     int f = (row & 3) | (((row >> 3) & 1) << 2);
@@ -1309,6 +1452,7 @@ static bool wgrad_use_v2(const sgg_conv_desc* d) {
 
 static int wgrad_splits(const sgg_conv_desc* d) {
     int64_t P = (int64_t)d->N * d->Ho * d->Wo;
+    if (halo_wgrad_ok(d)) return halo_wgrad_blocks(d);               // one slab per persistent block
     if (wgrad_use_v2(d)) {                                         // one 8-wave block per CU: ~256 blocks in all
         int64_t tiles = (int64_t)((d->R * d->S * d->C + 255) / 256) * ((d->K + 255) / 256);
         int64_t sp = 256 / tiles, maxs = (P + 127) / 128;
@@ -1336,6 +1480,23 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S; a.stride = d->stride;
     a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.reflect = d->pad_mode == SGG_PAD_REFLECT;
     a.P = d->N * d->Ho * d->Wo;
+    if (halo_wgrad_ok(d)) {
+        const int nb = halo_wgrad_blocks(d), ntiles = d->N * (d->H / HALO_TH) * (d->W / HALO_TW);
+        size_t need = (size_t)nb * d->R * d->S * d->C * d->K * sizeof(float);
+        if (ws_bytes < need || !ws) return SGG_EWORKSPACE;
+        a.pix_per_split = 0; a.dHW = make_fastdiv(1); a.dW = make_fastdiv(1);
+        size_t lds = 512 * 16 * sizeof(T) + (size_t)(HALO_TH + d->R - 1) * (HALO_TW + d->S - 1) * 128 + 1024;
+        auto kern = conv_halo_wgrad_kernel<T>;
+        static bool attr_done = false;
+        if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, s, a, ntiles);
+        int rc0 = sgg_check_launch();
+        if (rc0) return rc0;
+        int64_t total0 = (int64_t)d->R * d->S * Cr * (d->K / 4);
+        int blocks0 = (int)((total0 + 255) / 256); if (blocks0 > 4096) blocks0 = 4096;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks0), dim3(256), 0, s, (const float*)ws, dw, d->R * d->S, d->C, d->K, Cr, Kr, nb, accumulate);
+        return sgg_check_launch();
+    }
     int splits = wgrad_splits(d);
     a.pix_per_split = (int)align_up((size_t)((a.P + splits - 1) / splits), 64);
     splits = (a.P + a.pix_per_split - 1) / a.pix_per_split;

@@ -134,10 +134,27 @@ int sgg_mask_reduce_bwd(const float* dout, const float* mask, void* dh4, int N, 
  * dlogits[i] (+)= weight*gscale*(sigmoid(x_i)-label)/n.  accumulate bit0: add into *loss; bit1: add into dlogits. */
 int sgg_bce_logits(const float* logits, int64_t n, float label, float weight, float gscale, float* loss, float* dlogits,
                    int accumulate, void* stream);
-/* L1: *loss (+)= weight*mean_{p,c<C_real}|a-b|;  db = -weight*gscale*sign(a-b)/(P*C_real) (0 in padded channels). */
+/* L1 (abs_criterion, module.py:336-337): *loss (+)= weight*mean_{p,c<C_real}|a-b|;  db (+)= -weight*gscale*sign(a-b)/(P*C_real)
+ * (0 in padded channels).  accumulate bit0: add into *loss; bit1: add into db. */
 int sgg_l1_loss(const void* a, const void* b, int64_t P, int C_real, int Cpad, float weight, float gscale, float* loss,
                 void* db, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
 size_t sgg_l1_loss_workspace(int64_t P, int Cpad);
+
+/* ---- defined-not-wired SG-GAN criteria, used by the cycle-mode step ----
+ * LSGAN criterion against a constant target -- mae_criterion (module.py:340-341; squared error despite the name):
+ *   *loss (+)= weight*mean((x-t)^2);  dx (+)= weight*gscale*2(x-t)/n.  accumulate bits as sgg_bce_logits. */
+int sgg_mse_const(const float* x, int64_t n, float target, float weight, float gscale, float* loss, float* dx,
+                  int accumulate, void* stream);
+/* segmentation-edge indicator (model.py:108-119): 1 where the REFLECT-padded colour segmentation has a non-zero central
+ * difference in x or y on any channel, else 0.  seg (N,H,W,Cpad) in dtype -> out f32 (N,H,W). */
+int sgg_seg_edge_weight(const void* seg, float* out, int N, int H, int W, int C_real, int Cpad, int dtype, void* stream);
+/* gradient-sensitive loss -- tf_deriv + gradloss_criterion (module.py:325-351): Sobel gx/gy (depthwise, SAME zero pad) of
+ * `in` and `target`;  *loss (+)= lambda * mean_pixels( weight * mean_{2C}| |d(in)| - |d(target)| | );
+ * din (+)= gscale * d(lambda*loss)/d(in) (NULL: loss only).  accumulate bit0: loss, bit1: din. */
+size_t sgg_gradloss_workspace(int N, int H, int W, int C_real);
+int sgg_gradloss(const void* in, const void* target, const float* weight, int N, int H, int W, int C_real, int Cpad,
+                 float lambda, float gscale, float* loss, void* din, int accumulate, int dtype,
+                 void* ws, size_t ws_bytes, void* stream);
 
 /* ---- optimizer: tf.keras.optimizers.Adam.apply_gradients ---- model.py:199-200,205-207
  * Keras form, over one flat f32 buffer:  m=b1*m+(1-b1)*g; v=b2*v+(1-b2)*g^2;

@@ -580,3 +580,135 @@ def train_step(PG, PD, real_A, seg_A, mask_A, opt_state=None, t=1, lr=1e-3, beta
     return {"fake_A": fake.v, "da_real": da_real.v, "da_fake": da_fake.v,
             "gen_loss": float(gen_loss.v), "disc_loss": float(disc_loss.v),
             "gG": gG, "gD": gD, "PG": newG, "PD": newD, "opt_state": st}
+
+
+# ----------------------------------------------------------------------------
+# defined-not-wired SG-GAN pieces and the cycle-mode step built from them (deviation D5)
+# ----------------------------------------------------------------------------
+
+SOBEL_X = np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], F64)     # module.py:327-329
+SOBEL_Y = np.array([[-1, -2, -1], [0, 0, 0], [1, 2, 1]], F64)     # module.py:330-332
+
+
+def mse_const_mean(tape, x: Var, target: float) -> Var:
+    """``mae_criterion(in_, target)`` (module.py:340-341): reduce_mean((in_-target)**2) -- the LSGAN criterion
+    (squared error despite the name) against ones_like / zeros_like (model.py:121,127-128)."""
+    d = x.v - target
+    y = Var((d ** 2).mean())
+    tape.record(y, lambda gy: x.acc(gy * 2 * d / d.size))
+    return y
+
+
+def seg_edge_weight(seg: np.ndarray) -> np.ndarray:
+    """model.py:108-119: REFLECT-pad 1, depthwise central differences [[0,0,0],[-1,0,1],[0,0,0]] and its
+    transpose (VALID), abs, reduce_sum over channels (keepdims), sign, abs -> (N,H,W,1) in {0,1}."""
+    N, H, W, C = seg.shape
+    ih, iw = reflect_index(H, 1), reflect_index(W, 1)
+    sp = np.asarray(seg, F64)[:, ih][:, :, iw]
+    dx = sp[:, 1:H + 1, 2:W + 2] - sp[:, 1:H + 1, 0:W]
+    dy = sp[:, 2:H + 2, 1:W + 1] - sp[:, 0:H, 1:W + 1]
+    s = (np.abs(dx) + np.abs(dy)).sum(-1, keepdims=True)
+    return np.abs(np.sign(s))
+
+
+def _sobel(x):
+    """tf_deriv (module.py:325-334): depthwise correlation with gx, gy, padding SAME (zero); returns (gx, gy)."""
+    N, H, W, C = x.shape
+    xp = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    gx = np.zeros_like(x); gy = np.zeros_like(x)
+    for a in range(3):
+        for b in range(3):
+            sl = xp[:, a:a + H, b:b + W]
+            gx += SOBEL_X[a, b] * sl; gy += SOBEL_Y[a, b] * sl
+    return gx, gy
+
+
+def _sobel_T(ggx, ggy):
+    N, H, W, C = ggx.shape
+    gp = np.zeros((N, H + 2, W + 2, C))
+    for a in range(3):
+        for b in range(3):
+            gp[:, a:a + H, b:b + W] += SOBEL_X[a, b] * ggx + SOBEL_Y[a, b] * ggy
+    return gp[:, 1:H + 1, 1:W + 1]
+
+
+def gradloss(tape, in_: Var, target: np.ndarray, weight: np.ndarray) -> Var:
+    """gradloss_criterion (module.py:347-351): abs_deriv = | |tf_deriv(in_)| - |tf_deriv(target)| |,
+    reduce_mean over the 2C derivative channels (keepdims), reduce_mean(weight * abs_deriv)."""
+    ax, ay = _sobel(in_.v)
+    bx, by = _sobel(np.asarray(target, F64))
+    dx, dy = np.abs(ax) - np.abs(bx), np.abs(ay) - np.abs(by)
+    C = in_.v.shape[-1]
+    per = (np.abs(dx) + np.abs(dy)).sum(-1, keepdims=True) / (2 * C)
+    y = Var((weight * per).mean())
+
+    def vjp(gy_):
+        k = gy_ * weight / (2 * C) / weight.size
+        in_.acc(_sobel_T(k * np.sign(dx) * np.sign(ax), k * np.sign(dy) * np.sign(ay)))
+
+    tape.record(y, vjp)
+    return y
+
+
+def add_scalars(tape, terms) -> Var:
+    """sum_i coef_i * term_i on scalar Vars."""
+    y = Var(sum(c * t.v for c, t in terms))
+
+    def vjp(gy):
+        for c, t in terms:
+            t.acc(gy * c)
+
+    tape.record(y, vjp)
+    return y
+
+
+def cycle_step(PGab, PGba, PDa, PDb, real_A, real_B, seg_A, seg_B, mask_A, mask_B, opt_state=None, t=1,
+               lr=2e-4, beta1=0.5, L1_lambda=10.0, Lg_lambda=5.0, use_lsgan=True, n_blocks=9, leak=0.3, eps=1e-3):
+    """The 2G+2D SG-GAN step (north_star unit; deviation D5) assembled from the reference's defined-not-wired
+    criteria: generator_loss / discriminator_loss (model.py:114-133) with criterionGAN = mae_criterion (use_lsgan,
+    main.py:39) or sce_criterion, abs_criterion cycle terms weighted by --L1_lambda (main.py:37) and the
+    gradient-sensitive terms weighted by --Lg_lambda (main.py:38) on the seg-edge indicator (model.py:108-119);
+    Adam(lr=--lr, beta1) for all four networks.  Domain B fakes are judged on A's semantics (mask_A) and vice versa.
+    No image pool (ImagePool is never called in the reference), so D sees the current fakes."""
+    tape = Tape()
+    V = lambda P: {k: Var(v, k) for k, v in P.items()}
+    Gab, Gba, Da, Db = V(PGab), V(PGba), V(PDa), V(PDb)
+    xA, xB = Var(real_A), Var(real_B)
+    fake_B = generator_resnet(tape, Gab, xA, n_blocks, eps)
+    cyc_A = generator_resnet(tape, Gba, fake_B, n_blocks, eps)
+    fake_A = generator_resnet(tape, Gba, xB, n_blocks, eps)
+    cyc_B = generator_resnet(tape, Gab, fake_A, n_blocks, eps)
+    DB_fake = discriminator(tape, Db, fake_B, mask_A, leak, eps)
+    DA_fake = discriminator(tape, Da, fake_A, mask_B, leak, eps)
+    DA_real = discriminator(tape, Da, xA, mask_A, leak, eps)
+    DB_real = discriminator(tape, Db, xB, mask_B, leak, eps)
+    crit = (lambda x, z: mse_const_mean(tape, x, z)) if use_lsgan else (lambda x, z: bce_logits_mean(tape, x, z))
+    wA, wB = seg_edge_weight(seg_A), seg_edge_weight(seg_B)
+    g_loss = add_scalars(tape, [
+        (1.0, crit(DA_fake, 1.0)), (1.0, crit(DB_fake, 1.0)),
+        (L1_lambda, l1_mean(tape, np.asarray(real_A, F64), cyc_A)), (L1_lambda, l1_mean(tape, np.asarray(real_B, F64), cyc_B)),
+        (Lg_lambda, gradloss(tape, fake_A, real_B, wB)), (Lg_lambda, gradloss(tape, fake_B, real_A, wA))])
+    d_loss = add_scalars(tape, [(0.5, crit(DA_real, 1.0)), (0.5, crit(DA_fake, 0.0)),
+                                (0.5, crit(DB_real, 1.0)), (0.5, crit(DB_fake, 0.0))])
+
+    nets = {"Gab": Gab, "Gba": Gba, "Da": Da, "Db": Db}
+
+    def grads(loss, which):
+        for v in [xA, xB] + [p for n in nets.values() for p in n.values()] + [o for o, _ in tape.ops]:
+            v.g = None
+        tape.backward([(loss, 1.0)])
+        return {n: {k: (np.zeros_like(v.v) if v.g is None else v.g.copy()) for k, v in nets[n].items()} for n in which}
+
+    G = grads(g_loss, ("Gab", "Gba"))
+    G.update(grads(d_loss, ("Da", "Db")))
+    params = {"Gab": PGab, "Gba": PGba, "Da": PDa, "Db": PDb}
+    if opt_state is None:
+        opt_state = {n: {"m": {k: np.zeros_like(v) for k, v in P.items()}, "v": {k: np.zeros_like(v) for k, v in P.items()}}
+                     for n, P in params.items()}
+    new, st = {}, {}
+    for n, P in params.items():
+        new[n], st[n] = {}, {"m": {}, "v": {}}
+        for k in P:
+            new[n][k], st[n]["m"][k], st[n]["v"][k] = adam_tf(P[k], G[n][k], opt_state[n]["m"][k], opt_state[n]["v"][k], t, lr, beta1)
+    return {"fake_A": fake_A.v, "fake_B": fake_B.v, "cyc_A": cyc_A.v, "cyc_B": cyc_B.v, "g_loss": float(g_loss.v),
+            "d_loss": float(d_loss.v), "grads": G, "params": new, "opt_state": st}

@@ -56,6 +56,10 @@ SIGNATURES = {
     "sgg_bce_logits": (_i, [_vp, _i64, _f, _f, _f, _vp, _vp, _i, _vp]),
     "sgg_l1_loss_workspace": (_sz, [_i64, _i]),
     "sgg_l1_loss": (_i, [_vp, _vp, _i64, _i, _i, _f, _f, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "sgg_mse_const": (_i, [_vp, _i64, _f, _f, _f, _vp, _vp, _i, _vp]),
+    "sgg_seg_edge_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "sgg_gradloss_workspace": (_sz, [_i, _i, _i, _i]),
+    "sgg_gradloss": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "sgg_adam": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _vp]),
     "sgg_seg_class_map": (_i, [_vp, _i, _i64, _vp, _vp]),
     "sgg_seg_class_table": (_i, [_vp, _vp, _i]),

@@ -140,10 +140,121 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* x, int64_t
     if (threadIdx.x == 0 && loss) { float l = (float)(weight * red[0] / (double)n); *loss = (accumulate & 1) ? *loss + l : l; }
 }
 
+// LSGAN criterion against a constant target: mae_criterion (module.py:340-341) = mean((x - t)^2)  [sic: squared]
+__global__ __launch_bounds__(256) void mse_const_kernel(const float* x, int64_t n, float target, float weight, float gscale,
+                                                        float* loss, float* dx, int accumulate) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        float d = x[i] - target;
+        s += (double)(d * d);
+        float g = weight * gscale * 2.f * d / (float)n;
+        if (dx) dx[i] = (accumulate & 2) ? dx[i] + g : g;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0 && loss) { float l = (float)(weight * red[0] / (double)n); *loss = (accumulate & 1) ? *loss + l : l; }
+}
+
+// Segmentation-edge indicator (model.py:108-119): central differences along x and y of the REFLECT-padded colour
+// segmentation, |.| summed over channels, then sign -> 1 on class boundaries, 0 inside regions.  out f32 [N][H][W].
+template <typename T>
+__global__ __launch_bounds__(256) void seg_edge_kernel(const T* seg, float* out, int N, int H, int W, int Cr, int Cp) {
+    int64_t total = (int64_t)N * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int w = (int)(i % W), h = (int)((i / W) % H), n = (int)(i / ((int64_t)W * H));
+        int wl = w == 0 ? 1 : w - 1, wr = w == W - 1 ? W - 2 : w + 1;       // REFLECT (no edge repeat)
+        int hu = h == 0 ? 1 : h - 1, hd = h == H - 1 ? H - 2 : h + 1;
+        const T* b = seg + (size_t)n * H * W * Cp;
+        float s = 0.f;
+        for (int c = 0; c < Cr; ++c) {
+            s += fabsf((float)b[((size_t)h * W + wr) * Cp + c] - (float)b[((size_t)h * W + wl) * Cp + c]);
+            s += fabsf((float)b[((size_t)hd * W + w) * Cp + c] - (float)b[((size_t)hu * W + w) * Cp + c]);
+        }
+        out[i] = s > 0.f ? 1.f : 0.f;
+    }
+}
+
+// Gradient-sensitive loss (module.py:325-351): Sobel gx/gy (depthwise, SAME zero padding) of `in` and `target`,
+// abs_deriv = | |d(in)| - |d(target)| |, mean over the 2*C derivative channels, mean over pixels of weight*abs_deriv.
+template <typename T>
+__device__ inline void sobel_at(const T* img, int H, int W, int Cp, int h, int w, int c, float& gx, float& gy) {
+    float v[3][3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            int hh = h + dy - 1, ww = w + dx - 1;
+            v[dy][dx] = ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) ? (float)img[((size_t)hh * W + ww) * Cp + c] : 0.f;
+        }
+    gx = (v[0][2] - v[0][0]) + 2.f * (v[1][2] - v[1][0]) + (v[2][2] - v[2][0]);
+    gy = (v[2][0] - v[0][0]) + 2.f * (v[2][1] - v[0][1]) + (v[2][2] - v[0][2]);
+}
+
+// pass 1: per-pixel loss terms -> block partials; coef[p][c][2] = d loss / d (derivative of `in`) (if coef != null)
+template <typename T>
+__global__ __launch_bounds__(256) void gradloss_fwd_kernel(const T* in, const T* tgt, const float* weight, float* coef, float* partial,
+                                                           int N, int H, int W, int Cr, int Cp, float gval) {
+    int64_t total = (int64_t)N * H * W;
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int w = (int)(i % W), h = (int)((i / W) % H), n = (int)(i / ((int64_t)W * H));
+        const T* a = in + (size_t)n * H * W * Cp;
+        const T* b = tgt + (size_t)n * H * W * Cp;
+        float wt = weight[i], acc = 0.f;
+        for (int c = 0; c < Cr; ++c) {
+            float ax, ay, bx, by;
+            sobel_at(a, H, W, Cp, h, w, c, ax, ay);
+            sobel_at(b, H, W, Cp, h, w, c, bx, by);
+            float dx = fabsf(ax) - fabsf(bx), dy = fabsf(ay) - fabsf(by);
+            acc += fabsf(dx) + fabsf(dy);
+            if (coef) {
+                float sx = (dx > 0.f ? 1.f : (dx < 0.f ? -1.f : 0.f)) * (ax > 0.f ? 1.f : (ax < 0.f ? -1.f : 0.f));
+                float sy = (dy > 0.f ? 1.f : (dy < 0.f ? -1.f : 0.f)) * (ay > 0.f ? 1.f : (ay < 0.f ? -1.f : 0.f));
+                coef[(i * Cr + c) * 2] = gval * wt * sx;
+                coef[(i * Cr + c) * 2 + 1] = gval * wt * sy;
+            }
+        }
+        s += wt * acc;
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// pass 2: d in[q][c] = sum over the 3x3 neighbours p of coef[p][c][j] * K_j[q - p + 1]   (transpose of the Sobel correlation)
+template <typename T>
+__global__ __launch_bounds__(256) void gradloss_bwd_kernel(const float* coef, T* din, int N, int H, int W, int Cr, int Cp, int accumulate) {
+    const float KX[3][3] = {{-1.f, 0.f, 1.f}, {-2.f, 0.f, 2.f}, {-1.f, 0.f, 1.f}};
+    const float KY[3][3] = {{-1.f, -2.f, -1.f}, {0.f, 0.f, 0.f}, {1.f, 2.f, 1.f}};
+    int64_t total = (int64_t)N * H * W * Cp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % Cp);
+        int64_t px = i / Cp;
+        int w = (int)(px % W), h = (int)((px / W) % H), n = (int)(px / ((int64_t)W * H));
+        float g = 0.f;
+        if (c < Cr) {
+            for (int dy = 0; dy < 3; ++dy)
+                for (int dx = 0; dx < 3; ++dx) {
+                    // derivative at p = q - (dy-1, dx-1) read in[q] with kernel element K[dy][dx]
+                    int ph = h - (dy - 1), pw = w - (dx - 1);
+                    if ((unsigned)ph < (unsigned)H && (unsigned)pw < (unsigned)W) {
+                        size_t o = ((((size_t)n * H + ph) * W + pw) * Cr + c) * 2;
+                        g += coef[o] * KX[dy][dx] + coef[o + 1] * KY[dy][dx];
+                    }
+                }
+        }
+        din[i] = (T)(accumulate ? (float)din[i] + g : g);
+    }
+}
+
 #define L1_ROWS 2048
 template <typename T>
 __global__ __launch_bounds__(256) void l1_partial_kernel(const char* a, const char* b, char* db, float* partial, int64_t nvec,
-                                                         int Cr, int Cp, float gval) {
+                                                         int Cr, int Cp, float gval, int accdb) {
     constexpr int VEC = ET<T>::VEC;
     const int64_t i0 = (int64_t)blockIdx.x * L1_ROWS;
     const int64_t i1 = i0 + L1_ROWS < nvec ? i0 + L1_ROWS : nvec;
@@ -160,7 +271,12 @@ __global__ __launch_bounds__(256) void l1_partial_kernel(const char* a, const ch
             s += real ? fabsf(d) : 0.f;
             g[e] = real ? (d > 0.f ? -gval : (d < 0.f ? gval : 0.f)) : 0.f;      // d/db |a-b| = -sign(a-b)
         }
-        if (db) st16(db + i * 16, ET<T>::pack(g));
+        if (db) {
+            if (accdb) { float o[VEC]; ET<T>::unpack(ld16(db + i * 16), o);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) g[e] += o[e]; }
+            st16(db + i * 16, ET<T>::pack(g));
+        }
     }
     __shared__ float red[256];
     red[threadIdx.x] = s;
@@ -317,6 +433,49 @@ int sgg_bce_logits(const float* logits, int64_t n, float label, float weight, fl
     return sgg_check_launch();
 }
 
+int sgg_mse_const(const float* x, int64_t n, float target, float weight, float gscale, float* loss, float* dx, int accumulate, void* stream) {
+    if (!x || n <= 0) return SGG_EINVAL;
+    hipLaunchKernelGGL(mse_const_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, target, weight, gscale, loss, dx, accumulate);
+    return sgg_check_launch();
+}
+
+int sgg_seg_edge_weight(const void* seg, float* out, int N, int H, int W, int C_real, int Cpad, int dtype, void* stream) {
+    if (!seg || !out || N <= 0 || H < 2 || W < 2 || C_real <= 0 || Cpad < C_real) return SGG_EINVAL;
+    int64_t total = (int64_t)N * H * W;
+    if (dtype == SGG_BF16) hipLaunchKernelGGL(seg_edge_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16*)seg, out, N, H, W, C_real, Cpad);
+    else if (dtype == SGG_F32) hipLaunchKernelGGL(seg_edge_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)seg, out, N, H, W, C_real, Cpad);
+    else return SGG_EINVAL;
+    return sgg_check_launch();
+}
+
+#define GL_BLOCKS 1024
+size_t sgg_gradloss_workspace(int N, int H, int W, int C_real) {
+    if (N <= 0 || H <= 0 || W <= 0 || C_real <= 0) return 0;
+    return (size_t)N * H * W * C_real * 2 * sizeof(float) + GL_BLOCKS * sizeof(float);
+}
+int sgg_gradloss(const void* in, const void* target, const float* weight, int N, int H, int W, int C_real, int Cpad, float lambda,
+                 float gscale, float* loss, void* din, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (!in || !target || !weight || !loss || N <= 0 || H <= 0 || W <= 0 || C_real <= 0 || Cpad < C_real) return SGG_EINVAL;
+    if (!ws || ws_bytes < sgg_gradloss_workspace(N, H, W, C_real)) return SGG_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = (float*)ws;
+    float* coef = din ? partial + GL_BLOCKS : nullptr;
+    int64_t total = (int64_t)N * H * W;
+    int blocks = (int)((total + 255) / 256); if (blocks > GL_BLOCKS) blocks = GL_BLOCKS;
+    double denom = (double)total * (2.0 * C_real);               // mean over 2C derivative channels, then over pixels
+    float gval = (float)((double)lambda * gscale / denom);
+    if (dtype == SGG_BF16) hipLaunchKernelGGL(gradloss_fwd_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)in, (const bf16*)target, weight, coef, partial, N, H, W, C_real, Cpad, gval);
+    else if (dtype == SGG_F32) hipLaunchKernelGGL(gradloss_fwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)in, (const float*)target, weight, coef, partial, N, H, W, C_real, Cpad, gval);
+    else return SGG_EINVAL;
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, s, (const float*)partial, blocks, (double)lambda / denom, loss, accumulate & 1);
+    if (din) {
+        int64_t tot2 = total * Cpad;
+        if (dtype == SGG_BF16) hipLaunchKernelGGL(gradloss_bwd_kernel<bf16>, dim3(grid_for(tot2)), dim3(256), 0, s, (const float*)coef, (bf16*)din, N, H, W, C_real, Cpad, (accumulate >> 1) & 1);
+        else hipLaunchKernelGGL(gradloss_bwd_kernel<float>, dim3(grid_for(tot2)), dim3(256), 0, s, (const float*)coef, (float*)din, N, H, W, C_real, Cpad, (accumulate >> 1) & 1);
+    }
+    return sgg_check_launch();
+}
+
 size_t sgg_l1_loss_workspace(int64_t P, int Cpad) {
     if (P <= 0 || Cpad <= 0) return 0;
     int64_t nvec = P * Cpad / 4;      // worst case (f32)
@@ -332,10 +491,10 @@ int sgg_l1_loss(const void* a, const void* b, int64_t P, int Cr, int Cp, float w
     double cnt = (double)P * Cr;
     float gval = (float)((double)weight * gscale / cnt);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SGG_BF16) hipLaunchKernelGGL(l1_partial_kernel<bf16>, dim3(chunks), dim3(256), 0, s, (const char*)a, (const char*)b, (char*)db, (float*)ws, nvec, Cr, Cp, gval);
-    else if (dtype == SGG_F32) hipLaunchKernelGGL(l1_partial_kernel<float>, dim3(chunks), dim3(256), 0, s, (const char*)a, (const char*)b, (char*)db, (float*)ws, nvec, Cr, Cp, gval);
+    if (dtype == SGG_BF16) hipLaunchKernelGGL(l1_partial_kernel<bf16>, dim3(chunks), dim3(256), 0, s, (const char*)a, (const char*)b, (char*)db, (float*)ws, nvec, Cr, Cp, gval, (accumulate >> 1) & 1);
+    else if (dtype == SGG_F32) hipLaunchKernelGGL(l1_partial_kernel<float>, dim3(chunks), dim3(256), 0, s, (const char*)a, (const char*)b, (char*)db, (float*)ws, nvec, Cr, Cp, gval, (accumulate >> 1) & 1);
     else return SGG_EINVAL;
-    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, chunks, (double)weight / cnt, loss, accumulate);
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, chunks, (double)weight / cnt, loss, accumulate & 1);
     return sgg_check_launch();
 }
 

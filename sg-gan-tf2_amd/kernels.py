@@ -262,12 +262,36 @@ def bce_logits(logits, label, loss, dlogits=None, weight=1.0, gscale=1.0, accumu
                                    int(bool(accumulate_loss)) | (int(bool(accumulate_grad)) << 1), _s()), "bce_logits")
 
 
-def l1_loss(a, b, C_real, loss, db=None, weight=1.0, gscale=1.0, accumulate=False):
+def l1_loss(a, b, C_real, loss, db=None, weight=1.0, gscale=1.0, accumulate=False, accumulate_grad=False):
     Cp = a.shape[-1]
     P = a.numel() // Cp
     ws = workspace(int(A.lib().sgg_l1_loss_workspace(P, Cp)), a.device)
-    A.check(A.lib().sgg_l1_loss(_p(a), _p(b), P, C_real, Cp, float(weight), float(gscale), _p(loss), _p(db), int(accumulate), dt(a),
-                                _p(ws), ws.numel(), _s()), "l1_loss")
+    A.check(A.lib().sgg_l1_loss(_p(a), _p(b), P, C_real, Cp, float(weight), float(gscale), _p(loss), _p(db),
+                                int(bool(accumulate)) | (int(bool(accumulate_grad)) << 1), dt(a), _p(ws), ws.numel(), _s()), "l1_loss")
+
+
+def mse_const(x, target, loss, dx=None, weight=1.0, gscale=1.0, accumulate_loss=False, accumulate_grad=False):
+    """mae_criterion(x, target*ones) (module.py:340-341): mean squared error against a constant."""
+    assert x.dtype == torch.float32
+    A.check(A.lib().sgg_mse_const(_p(x), x.numel(), float(target), float(weight), float(gscale), _p(loss), _p(dx),
+                                  int(bool(accumulate_loss)) | (int(bool(accumulate_grad)) << 1), _s()), "mse_const")
+
+
+def seg_edge_weight(seg, C_real):
+    """model.py:108-119 weighted_seg: (N,H,W,Cp) colour segmentation -> f32 (N,H,W) edge indicator."""
+    N, H, W, Cp = seg.shape
+    out = torch.empty((N, H, W), dtype=torch.float32, device=seg.device)
+    A.check(A.lib().sgg_seg_edge_weight(_p(seg), _p(out), N, H, W, C_real, Cp, dt(seg), _s()), "seg_edge_weight")
+    return out
+
+
+def gradloss(x, target, weight, C_real, loss, dx=None, lam=1.0, gscale=1.0, accumulate_loss=False, accumulate_grad=False):
+    """gradloss_criterion (module.py:347-351) scaled by lam; optional gradient w.r.t. x."""
+    N, H, W, Cp = x.shape
+    need = int(A.lib().sgg_gradloss_workspace(N, H, W, C_real))
+    ws = workspace(need, x.device)
+    A.check(A.lib().sgg_gradloss(_p(x), _p(target), _p(weight), N, H, W, C_real, Cp, float(lam), float(gscale), _p(loss), _p(dx),
+                                 int(bool(accumulate_loss)) | (int(bool(accumulate_grad)) << 1), dt(x), _p(ws), ws.numel(), _s()), "gradloss")
 
 
 def adam(theta, g, m, v, t, lr=1e-3, beta1=0.5, beta2=0.999, eps=1e-7, grad_scale=1.0):

@@ -58,6 +58,17 @@ class sggan(object):
                                    n_blocks=g("n_blocks", 9), dtype=self.dtype, device=self.device, seed=seed)  # :56
         self.beta1 = g("beta1", 0.5)
         self.lr = self.LR
+        # cycle mode (north_star unit, deviation D5): G_A->B = self.generator, D_A = self.discriminator, plus G_B->A and D_B
+        self.cycle = bool(g("cycle", False))
+        self.L1_lambda, self.Lg_lambda = float(g("L1_lambda", 10.0)), float(g("Lg_lambda", 5.0))
+        self.use_lsgan = bool(g("use_lsgan", True))
+        self.cycle_lr = float(g("lr", 0.0002))
+        if self.cycle:
+            self.generator_BA = Generator(gf_dim=g("ngf", 64), in_c=self.output_c_dim, out_c=self.input_c_dim,
+                                          n_blocks=g("n_blocks", 9), dtype=self.dtype, device=self.device, seed=seed + 2)
+            self.discriminator_B = Discriminator(df_dim=g("ndf", 64), in_c=self.output_c_dim, segment_class=self.segment_class,
+                                                 dtype=self.dtype, device=self.device, seed=seed + 3)
+            self.real_B = self.seg_B = self.mask_B = self.fake_B = None
         # step I/O attributes (model.py:250-256 sets the inputs; :260 reads the losses)
         self.real_A = self.seg_A = self.mask_A = self.fake_A = None
         self._loss = torch.zeros(2, dtype=torch.float32, device=self.device)    # [gen_loss, disc_loss] on device
@@ -72,7 +83,7 @@ class sggan(object):
         from .dp import GradExchange
         self._dp = GradExchange(process_group)
         self._world = self._dp.world
-        for net in (self.generator, self.discriminator):       # identical replicas: broadcast rank 0's parameters
+        for net in self.networks():                             # identical replicas: broadcast rank 0's parameters
             self._dp.broadcast_(net.P.flat)
             net.P.version += 1
         return self
@@ -88,6 +99,8 @@ class sggan(object):
     def train_step(self, args=None):
         """model.py:169-200.  Reads ``real_A, seg_A`` (N,H,W,3) in [0,1] and ``mask_A`` (N,mh,mw,C);
         writes ``fake_A, gen_loss, disc_loss``; updates G, D and both Adam states."""
+        if self.cycle:
+            return self._train_step_cycle()
         G, D = self.generator, self.discriminator
         real, seg = self._prep(self.real_A), self._prep(self.seg_A)
         mask = self.mask_A if isinstance(self.mask_A, torch.Tensor) else torch.as_tensor(np.asarray(self.mask_A, dtype=np.float32))
@@ -130,6 +143,76 @@ class sggan(object):
         self._fake_internal = fake
         self.fake_A = _LazyUnpad(fake, self.output_c_dim)
         self.da_real, self.da_fake = da_real, da_fake
+        return self.gen_loss, self.disc_loss
+
+    def networks(self):
+        return (self.generator, self.discriminator) + ((self.generator_BA, self.discriminator_B) if self.cycle else ())
+
+    def _train_step_cycle(self):
+        """2G+2D step assembled from the reference's defined-not-wired criteria (deviation D5):
+        generator_loss / discriminator_loss (model.py:114-133) with criterionGAN = mae_criterion (--use_lsgan) or
+        sce_criterion, abs_criterion cycle terms x --L1_lambda, gradloss_criterion x --Lg_lambda weighted by the
+        segmentation-edge indicator (model.py:108-119).  Fakes in domain B are judged on A's mask and vice versa."""
+        Gab, Gba, Da, Db = self.generator, self.generator_BA, self.discriminator, self.discriminator_B
+        prep_mask = lambda m: (m if isinstance(m, torch.Tensor) else torch.as_tensor(np.asarray(m, dtype=np.float32))).to(
+            device=self.device, dtype=torch.float32).contiguous()
+        rA, rB = self._prep(self.real_A), self._prep(self.real_B)
+        sA, sB = self._prep(self.seg_A), self._prep(self.seg_B)
+        mA, mB = prep_mask(self.mask_A), prep_mask(self.mask_B)
+        for net in (Gab, Gba, Da, Db):
+            net.P.zero_grad()
+        C = self.output_c_dim
+
+        fake_B, t1 = Gab.forward(rA)
+        cyc_A, t4 = Gba.forward(fake_B)
+        fake_A, t3 = Gba.forward(rB)
+        cyc_B, t2 = Gab.forward(fake_A)
+        DB_fake, tDBf = Db.forward(fake_B, mA)
+        DA_fake, tDAf = Da.forward(fake_A, mB)
+        DA_real, tDAr = Da.forward(rA, mA)
+        DB_real, tDBr = Db.forward(rB, mB)
+        wA, wB = K.seg_edge_weight(sA, C), K.seg_edge_weight(sB, C)
+
+        crit = K.mse_const if self.use_lsgan else K.bce_logits
+        gl, dl = self._loss[0:1], self._loss[1:2]
+        e = torch.empty_like
+        gA_g, gB_g = e(DA_fake), e(DB_fake)                  # d g_loss / d logits
+        dA_r, dA_f, dB_r, dB_f = e(DA_real), e(DA_fake), e(DB_real), e(DB_fake)   # d d_loss / d logits
+        crit(DA_fake, 1.0, gl, gA_g)
+        crit(DB_fake, 1.0, gl, gB_g, accumulate_loss=True)
+        d_cycA, d_cycB = e(cyc_A), e(cyc_B)
+        K.l1_loss(rA, cyc_A, C, gl, d_cycA, weight=self.L1_lambda, accumulate=True)
+        K.l1_loss(rB, cyc_B, C, gl, d_cycB, weight=self.L1_lambda, accumulate=True)
+        d_fA, d_fB = e(fake_A), e(fake_B)                    # gradient-sensitive terms write, the rest accumulate
+        K.gradloss(fake_A, rB, wB, C, gl, d_fA, lam=self.Lg_lambda, accumulate_loss=True)
+        K.gradloss(fake_B, rA, wA, C, gl, d_fB, lam=self.Lg_lambda, accumulate_loss=True)
+        crit(DA_real, 1.0, dl, dA_r, weight=0.5)
+        crit(DA_fake, 0.0, dl, dA_f, weight=0.5, accumulate_loss=True)
+        crit(DB_real, 1.0, dl, dB_r, weight=0.5, accumulate_loss=True)
+        crit(DB_fake, 0.0, dl, dB_f, weight=0.5, accumulate_loss=True)
+
+        # discriminator gradients (fakes are constants here)
+        Da.backward(tDAr, dA_r); Da.backward(tDAf, dA_f)
+        hDa = self._allreduce(Da)
+        Db.backward(tDBr, dB_r); Db.backward(tDBf, dB_f)
+        hDb = self._allreduce(Db)
+        # generator gradients: cycle terms first (they reach the other generator through the fakes)
+        d_fB = K.add(d_fB, Gba.backward(t4, d_cycA, want_dx=True))
+        d_fA = K.add(d_fA, Gab.backward(t2, d_cycB, want_dx=True))
+        d_fB = K.add(d_fB, Db.backward(tDBf, gB_g, want_dx=True, param_grads=False))
+        d_fA = K.add(d_fA, Da.backward(tDAf, gA_g, want_dx=True, param_grads=False))
+        Gba.backward(t3, d_fA)
+        hGba = self._allreduce(Gba)
+        Gab.backward(t1, d_fB)
+        hGab = self._allreduce(Gab)
+
+        scale = 1.0 / self._world
+        for net, h in ((Da, hDa), (Db, hDb), (Gba, hGba), (Gab, hGab)):
+            if h is not None:
+                h.wait()
+            net.P.adam_step(self.cycle_lr, self.beta1, grad_scale=scale)
+        self.fake_A, self.fake_B = _LazyUnpad(fake_A, self.input_c_dim), _LazyUnpad(fake_B, C)
+        self.cyc_A, self.cyc_B = _LazyUnpad(cyc_A, self.input_c_dim), _LazyUnpad(cyc_B, C)
         return self.gen_loss, self.disc_loss
 
     # ------------------------------------------------------------------ convenience

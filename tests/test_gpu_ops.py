@@ -289,3 +289,37 @@ def test_abi_rejects_bad_arguments(sg):
         K.mask_reduce_fwd(torch.zeros(1, 2, 2, 40, device="cuda"), torch.zeros(1, 3, 3, 34, device="cuda"), 34)
     with pytest.raises(TypeError):
         K.act_fwd(torch.zeros(8, device="cuda", dtype=torch.float16), 1)
+
+
+def test_cycle_criteria_mse_edge_gradloss(sg):
+    """Defined-not-wired SG-GAN criteria: mae_criterion, seg-edge indicator, gradloss_criterion."""
+    from sggan_amd import kernels as K
+    rng = np.random.default_rng(12)
+    loss = torch.zeros(1, device="cuda")
+    x = rng.standard_normal((2, 5, 13, 1)) * 2
+    for tgt in (1.0, 0.0):
+        t = O.Tape(); vx = V(x); l = O.mse_const_mean(t, vx, tgt); t.backward([(l, 0.5)])
+        dx = torch.empty(x.shape, device="cuda")
+        K.mse_const(dev(x), tgt, loss, dx, weight=0.5)
+        assert abs(loss.item() - 0.5 * l.v) < 1e-6 * max(1, l.v)
+        close(dx.cpu().numpy(), vx.g, torch.float32, "dmse")
+    # edge indicator: blocky colour map, exact {0,1} equality
+    pal = rng.integers(0, 256, (6, 3)) / 255.0
+    idx = np.repeat(np.repeat(rng.integers(0, 6, (2, 4, 6)), 8, 1), 8, 2)
+    seg = pal[idx]
+    for dtype in DT:
+        got = K.seg_edge_weight(dev(np.pad(seg, ((0, 0),) * 3 + ((0, 5),)), dtype), 3).cpu().numpy()
+        assert np.array_equal(got, O.seg_edge_weight(seg)[..., 0])
+    # gradient-sensitive loss, forward and d/d(in)
+    for dtype in DT:
+        a = np.zeros((2, 16, 24, 8)); b = np.zeros((2, 16, 24, 8))
+        a[..., :3] = np.tanh(rng.standard_normal((2, 16, 24, 3))); b[..., :3] = rng.uniform(0, 1, (2, 16, 24, 3))
+        ta, tb = dev(a, dtype), dev(b, dtype)
+        aq = ta.float().cpu().numpy().astype(np.float64)[..., :3]; bq = tb.float().cpu().numpy().astype(np.float64)[..., :3]
+        w = (rng.uniform(size=(2, 16, 24, 1)) > 0.4) * 1.0
+        t = O.Tape(); va = V(aq); l = O.gradloss(t, va, bq, w); t.backward([(l, 5.0)])
+        da = torch.empty_like(ta)
+        K.gradloss(ta, tb, dev(w[..., 0]), 3, loss, da, lam=5.0)
+        assert abs(loss.item() - 5 * l.v) < (1e-5 if dtype == torch.float32 else 1e-3) * 5 * l.v
+        close(da.float().cpu().numpy()[..., :3], va.g, dtype, "dgradloss")
+        assert float(da.float()[..., 3:].abs().max()) == 0.0

@@ -200,3 +200,46 @@ def test_bench_size_bf16_step_runs_and_is_sane(sg):
     yf = y.float()
     want_var = 1 - 1e-3 * st[..., 1] ** 2                  # var/(var+eps) with rstd^2 = 1/(var+eps)
     assert yf.mean((1, 2)).abs().max() < 2e-2 and (yf.var((1, 2), unbiased=False) - want_var).abs().max() < 3e-2
+
+
+def test_cycle_step_small_f32_matches_oracle(sg):
+    """2G+2D cycle-mode step (deviation D5) vs the oracle's cycle_step on reduced networks, LSGAN and SCE criteria."""
+    rng = np.random.default_rng(23)
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    gs = O.generator_param_shapes(gf_dim=8, n_blocks=1); ds = O.discriminator_param_shapes(df_dim=8)
+    N, H, W = 1, 256, 256
+    for use_lsgan in (True, False):
+        P = {n: {k: f32(v) for k, v in O.init_params(sh, rng, 0.1).items()} for n, sh in (("Gab", gs), ("Gba", gs), ("Da", ds), ("Db", ds))}
+        real_A, real_B = f32(rng.uniform(0, 1, (N, H, W, 3))), f32(rng.uniform(0, 1, (N, H, W, 3)))
+        pal = rng.integers(0, 256, (8, 3)) / 255.0
+        blocks = lambda: f32(pal[np.repeat(np.repeat(rng.integers(0, 8, (N, 8, 8)), 32, 1), 32, 2)])
+        seg_A, seg_B = blocks(), blocks()
+        mk = lambda: np.stack([O.one_hot(i, 34) for i in rng.integers(0, 34, (N, 5, 5))]).astype(np.float64)
+        mask_A, mask_B = mk(), mk()
+        r = O.cycle_step(P["Gab"], P["Gba"], P["Da"], P["Db"], real_A, real_B, seg_A, seg_B, mask_A, mask_B,
+                         use_lsgan=use_lsgan, n_blocks=1)
+        m = sg.sggan(sg.default_args(ngf=8, ndf=8, n_blocks=1, dtype="f32", cycle=True, use_lsgan=use_lsgan))
+        nets = {"Gab": m.generator, "Gba": m.generator_BA, "Da": m.discriminator, "Db": m.discriminator_B}
+        for n, net in nets.items():
+            net.P.load(P[n])
+        m.real_A, m.real_B, m.seg_A, m.seg_B, m.mask_A, m.mask_B = real_A, real_B, seg_A, seg_B, mask_A, mask_B
+        m.train_step()
+        gl, dl = m.losses()
+        assert abs(gl - r["g_loss"]) < 2e-5 * abs(r["g_loss"]) and abs(dl - r["d_loss"]) < 2e-5 * abs(r["d_loss"]), (gl, r["g_loss"], dl, r["d_loss"])
+        assert rel(m.fake_B.numpy(), r["fake_B"]) < 1e-4 and rel(m.cyc_A.numpy(), r["cyc_A"]) < 2e-4
+        for n, net in nets.items():
+            got = net.P.export(net.P.grad)
+            for k, e in r["grads"][n].items():
+                if np.abs(e).max() < 1e-9:
+                    continue
+                # sign() in the L1 / gradient-sensitive terms makes the gradient piecewise constant in the fakes:
+                # f32-vs-f64 differences flip a few near-zero elements
+                assert rel(got[k], e) < 5e-3, (use_lsgan, n, k, rel(got[k], e))
+            new = net.P.export()
+            for k, e in r["params"][n].items():
+                ge = r["grads"][n][k]
+                if np.abs(ge).max() < 1e-9:
+                    continue
+                # Adam's first step is -lr*sign(g): elements whose gradient is at rounding-noise level may flip
+                sig = np.abs(ge) > 1e-3 * np.abs(ge).max()
+                assert np.abs(new[k] - e)[sig].max() < 2e-5, (n, k)

@@ -5,10 +5,13 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one reference-mode ``train_step`` (model.py:169-200: G fwd, D on real+fake, both losses, both
-gradient sets, both Adam updates) over one synthetic batch that is already resident in HBM.  Workload =
-BASELINE.json configs[2]: 512x256 (W x H) images, batch 8 per GPU, bf16 storage / f32 accumulate, 9-block
-ResNet generator; weak scaling (8 images per GPU), gradients averaged with one RCCL all-reduce per network.
+A "step" (default ``--mode cycle``) is the north_star unit of work: one G_A->B + G_B->A + D_A + D_B
+forward/backward/Adam step (4 generator passes, 4 discriminator passes, LSGAN + cycle-L1 + gradient-sensitive
+losses; ``sggan._train_step_cycle``) over one synthetic (A,B) batch already resident in HBM; one *image* = one
+A sample (a B sample is consumed with it).  ``--mode reference`` times the literal ``model.py:169-200`` step
+(1 G + 1 D, paired losses) instead; at N=1 it is also reported beside the headline as ``reference_mode_step``.
+Workload = BASELINE.json configs[2]: 512x256 (W x H) images, batch 8 per GPU, bf16 storage / f32 accumulate,
+9-block ResNet generators; weak scaling (8 images per GPU), one RCCL all-reduce per network bucket.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying two extra objects:
   roofline     -- the dominant kernel (3x3 C=256 residual-block conv forward, implicit GEMM M=N*64*128, N=256,
@@ -36,11 +39,15 @@ G_GMAC_256x512 = 99.103
 D_GMAC = {(128, 128): 0.599, (256, 256): 2.550, (256, 512): 5.189, (512, 1024): 21.375}
 
 
-def step_gflop_per_image(H, W):
+def step_gflop_per_image(H, W, mode="reference"):
     g = G_GMAC_256x512 * (H * W) / (256 * 512)
     d = D_GMAC.get((H, W))
     if d is None:
         d = 5.189 * (H * W) / (256 * 512)
+    if mode == "cycle":
+        # 4 G fwd + 4 G bwd (2x) = 12G;  D: 4 fwd + 4 full bwd (2x) + 2 data-gradient passes for the G loss = 14D
+        # (SURVEY.md 8(d) counts 16D: it evaluates D on the fakes twice; the build evaluates them once -- D2)
+        return 2.0 * (12 * g + 14 * d)
     return 2.0 * (3 * g + 7 * d)          # reference-mode step: 3G + 7D MACs
 
 
@@ -62,6 +69,24 @@ def synthetic_batch(model, N, H, W, seed):
     real_i = model.generator.to_internal(real.to(model.device))
     seg_i = model.generator.to_internal(seg.to(model.device))
     return real_i, seg_i, mask, (real, seg, mask.cpu())
+
+
+def set_inputs(model, N, H, W, seed):
+    a = synthetic_batch(model, N, H, W, seed)
+    model.real_A, model.seg_A, model.mask_A = a[0], a[1], a[2]
+    if model.cycle:
+        b = synthetic_batch(model, N, H, W, seed + 1000)
+        model.real_B, model.seg_B, model.mask_B = b[0], b[1], b[2]
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json: FETCH_SIZE doubled per
+    MI355X_MICROARCH.md + WRITE_SIZE, separate --pmc passes on tools/bench_conv.py); None if not collected."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            return json.load(f)[kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 class EventProfiler:
@@ -113,8 +138,30 @@ class EventProfiler:
         return out
 
 
+def cpu_baseline_cycle(H, W, seed):
+    """PyTorch-CPU f32 restatement of the cycle-mode step at N=1 (kind "port"): 1 warm-up + 1 timed step."""
+    from oracle import torch_restatement as T
+    from oracle import sggan_oracle as O
+    rng = np.random.default_rng(seed)
+    gs, ds = O.generator_param_shapes(), O.discriminator_param_shapes()
+    P = {n: O.init_params(sh, rng) for n, sh in (("Gab", gs), ("Gba", gs), ("Da", ds), ("Db", ds))}
+    img = lambda: rng.uniform(0, 1, (1, H, W, 3)).astype(np.float32)
+    mh, mw = O.disc_out_hw(H, W)
+    mk = lambda: np.stack([O.one_hot(rng.integers(0, 34, (mh, mw)), 34)]).astype(np.float32)
+    inputs = (img(), img(), img(), img(), mk(), mk())
+    S = T.CycleStep(P, torch.float32)
+    S.step(*inputs)
+    t1 = time.time()
+    S.step(*inputs)
+    dt = time.time() - t1
+    return {"value": 1.0 / dt, "unit": "images/sec", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"1 cycle-mode step (2G+2D) of N=1 {W}x{H} f32 (PyTorch-CPU restatement, oracle/torch_restatement.py "
+                      f"CycleStep; not TF2) after 1 warm-up; os.cpu_count()={os.cpu_count()}",
+            "gflops": step_gflop_per_image(H, W, "cycle") / dt}
+
+
 def cpu_baseline(H, W, seed, max_seconds=30.0):
-    """The PyTorch-CPU f32 restatement of the same step at N=1 (kind "port"), median of up to 3 steps after 1 warm-up."""
+    """The PyTorch-CPU f32 restatement of the reference-mode step at N=1 (kind "port"), median of up to 3 steps after 1 warm-up."""
     from oracle import torch_restatement as T
     from oracle import sggan_oracle as O
     rng = np.random.default_rng(seed)
@@ -151,6 +198,7 @@ def main():
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--mode", default="cycle", choices=["cycle", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -169,12 +217,15 @@ def main():
 
     import sggan_amd
     from sggan_amd import kernels as K
-    model = sggan_amd.sggan(sggan_amd.default_args(dtype=a.dtype, device=f"cuda:{local}", image_height=a.height,
-                                                   image_width=a.width, batch_size=a.batch))
-    if world > 1:
-        model.enable_data_parallel()
-    real, seg, mask, _ = synthetic_batch(model, a.batch, a.height, a.width, 19 + rank)
-    model.real_A, model.seg_A, model.mask_A = real, seg, mask
+    def make_model(mode):
+        m = sggan_amd.sggan(sggan_amd.default_args(dtype=a.dtype, device=f"cuda:{local}", image_height=a.height,
+                                                   image_width=a.width, batch_size=a.batch, cycle=(mode == "cycle")))
+        if world > 1:
+            m.enable_data_parallel()
+        set_inputs(m, a.batch, a.height, a.width, 19 + rank)
+        return m
+
+    model = make_model(a.mode)
 
     prof = EventProfiler((a.height // 4, a.width // 4))
     K.PROFILE = prof
@@ -206,13 +257,16 @@ def main():
     if rank == 0:
         images = a.batch * world * a.steps
         ips = images / elapsed
-        gflop_img = step_gflop_per_image(a.height, a.width)
+        gflop_img = step_gflop_per_image(a.height, a.width, a.mode)
+        what = ("cycle-mode train step (north_star unit: G_A->B + G_B->A + D_A + D_B, LSGAN + cycle-L1 + gradient-sensitive "
+                "losses; 12G+14D conv MACs)" if a.mode == "cycle" else
+                "reference-mode train_step (model.py:169-200; 1 G + 1 D, paired losses; 3G+7D conv MACs)")
         line = {
             "metric": "train-step images/sec (G+D fwd/bwd) at 512x256", "value": ips, "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: reference-mode train_step (model.py:169-200; 1 G + 1 D, 9-block ResNet G), "
-                                   f"{a.width}x{a.height}, batch {a.batch}/GPU, {a.dtype} storage / f32 accumulate",
+            "config": {"workload": f"BASELINE configs[2]: {what}, 9-block ResNet generators, "
+                                   f"{a.width}x{a.height}, batch {a.batch}/GPU, {a.dtype} storage / f32 accumulate", "mode": a.mode,
                        "global_batch": a.batch * world, "height": a.height, "width": a.width, "parallelism": f"dp{world}",
                        "gflop_per_image": gflop_img},
             "step_tflops": ips * gflop_img / 1e3,
@@ -230,9 +284,9 @@ def main():
                 kt[tag[0]] = {"avg_ms": ms, "launches": n, "gbs": by / (ms * 1e-3) / 1e9, "mbytes_per_launch": by / 1e6}
         if "res_conv_fwd" in kt:
             k = kt["res_conv_fwd"]
-            line["roofline"] = {"bound": "mfma", "kernel": "conv_gemm_kernel<bf16,FWD,128,128> (3x3 C=256 residual-block conv)",
+            line["roofline"] = {"bound": "mfma", "kernel": "conv_gemm_glds_kernel<bf16,FWD,256,256,8 waves> (3x3 C=256 residual-block conv)",
                                 "achieved": k["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                "frac": k["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
+                                "frac": k["tflops"] / PEAK_BF16_TFLOPS, "traffic": measured_traffic("res_conv_fwd"),
                                 "avg_launch_ms": k["avg_ms"], "launches_timed": k["launches"], "gflop_per_launch": k["gflop_per_launch"]}
         else:
             line["roofline"] = None
@@ -243,9 +297,29 @@ def main():
                                          "note": "3 launches (partial stats, finalize, apply); algorithmic bytes = 2 reads + 1 write"}
         line["kernels"] = kt
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(a.height, a.width, 19)
+            line["cpu_baseline"] = cpu_baseline_cycle(a.height, a.width, 19) if a.mode == "cycle" else cpu_baseline(a.height, a.width, 19)
         else:
             line["cpu_baseline"] = None
+        line["_pending_reference"] = (world == 1 and a.mode == "cycle")
+        if line.pop("_pending_reference"):
+            # the literal reference step (1 G + 1 D) beside the headline, same shapes, short run
+            K.PROFILE = None
+            del model
+            torch.cuda.empty_cache()
+            ref = make_model("reference")
+            for _ in range(3):
+                ref.train_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nref = max(5, a.steps // 2)
+            for _ in range(nref):
+                ref.train_step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / nref
+            gf = step_gflop_per_image(a.height, a.width, "reference")
+            line["reference_mode_step"] = {"images_per_sec": a.batch / dt, "ms_per_step": 1e3 * dt, "gflop_per_image": gf,
+                                           "step_tflops": a.batch / dt * gf / 1e3, "steps": nref,
+                                           "what": "model.py:169-200 (1 G + 1 D, BCE + 100*L1), same shapes and dtype"}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -128,3 +128,67 @@ class RefStep:
                 for (k, p), g in zip(self.PD.items(), gD):
                     adam_tf_(p, g, self.mD[k], self.vD[k], self.t, self.lr, self.beta1)
         return out
+
+
+# ---------------------------------------------------------------------------- cycle mode (2G+2D, deviation D5)
+def seg_edge_weight(seg):
+    """model.py:108-119 (NCHW): REFLECT-pad 1, central differences in x and y, |.| summed over channels, sign."""
+    sp = F.pad(seg, (1, 1, 1, 1), mode="reflect")
+    dx = sp[:, :, 1:-1, 2:] - sp[:, :, 1:-1, :-2]
+    dy = sp[:, :, 2:, 1:-1] - sp[:, :, :-2, 1:-1]
+    return (dx.abs() + dy.abs()).sum(1, keepdim=True).sign().abs()
+
+
+def gradloss(x, target, weight):
+    """gradloss_criterion / tf_deriv (module.py:325-351) in NCHW via a grouped (depthwise) conv, SAME zero padding."""
+    C = x.shape[1]
+    kx = torch.tensor([[-1., 0., 1.], [-2., 0., 2.], [-1., 0., 1.]], dtype=x.dtype)
+    ky = torch.tensor([[-1., -2., -1.], [0., 0., 0.], [1., 2., 1.]], dtype=x.dtype)
+    k = torch.stack([kx, ky]).repeat(C, 1, 1).unsqueeze(1)            # (2C,1,3,3): channel c -> outputs 2c, 2c+1
+    d = lambda t: F.conv2d(t, k, padding=1, groups=C)
+    a = (d(x).abs() - d(target).abs()).abs().mean(1, keepdim=True)
+    return (weight * a).mean()
+
+
+class CycleStep:
+    """Stateful cycle-mode step on CPU -- same definition as oracle.sggan_oracle.cycle_step."""
+
+    def __init__(self, P, dtype=torch.float32, lr=2e-4, beta1=0.5, L1_lambda=10.0, Lg_lambda=5.0, use_lsgan=True, n_blocks=9):
+        mk = lambda d: {k: torch.as_tensor(v).to(dtype).clone().requires_grad_(True) for k, v in d.items()}
+        self.P = {n: mk(P[n]) for n in ("Gab", "Gba", "Da", "Db")}
+        self.m = {n: {k: torch.zeros_like(v) for k, v in p.items()} for n, p in self.P.items()}
+        self.v = {n: {k: torch.zeros_like(v) for k, v in p.items()} for n, p in self.P.items()}
+        self.t, self.lr, self.beta1, self.dtype, self.n_blocks = 0, lr, beta1, dtype, n_blocks
+        self.L1, self.Lg, self.use_lsgan = L1_lambda, Lg_lambda, use_lsgan
+
+    def step(self, real_A, real_B, seg_A, seg_B, mask_A, mask_B):
+        to = lambda a: torch.as_tensor(a).to(self.dtype).permute(0, 3, 1, 2).contiguous()
+        rA, rB, sA, sB, mA, mB = map(to, (real_A, real_B, seg_A, seg_B, mask_A, mask_B))
+        P, nb = self.P, self.n_blocks
+        fake_B = generator_resnet(P["Gab"], rA, nb); cyc_A = generator_resnet(P["Gba"], fake_B, nb)
+        fake_A = generator_resnet(P["Gba"], rB, nb); cyc_B = generator_resnet(P["Gab"], fake_A, nb)
+        DB_fake = discriminator(P["Db"], fake_B, mA); DA_fake = discriminator(P["Da"], fake_A, mB)
+        DA_real = discriminator(P["Da"], rA, mA); DB_real = discriminator(P["Db"], rB, mB)
+        if self.use_lsgan:
+            crit = lambda x, z: ((x - z) ** 2).mean()
+        else:
+            crit = lambda x, z: F.binary_cross_entropy_with_logits(x, torch.full_like(x, z))
+        wA, wB = seg_edge_weight(sA), seg_edge_weight(sB)
+        g_loss = (crit(DA_fake, 1.0) + crit(DB_fake, 1.0) + self.L1 * ((rA - cyc_A).abs().mean() + (rB - cyc_B).abs().mean())
+                  + self.Lg * (gradloss(fake_A, rB, wB) + gradloss(fake_B, rA, wA)))
+        d_loss = 0.5 * (crit(DA_real, 1.0) + crit(DA_fake, 0.0)) + 0.5 * (crit(DB_real, 1.0) + crit(DB_fake, 0.0))
+        gp = list(P["Gab"].values()) + list(P["Gba"].values())
+        dp = list(P["Da"].values()) + list(P["Db"].values())
+        gg = torch.autograd.grad(g_loss, gp, retain_graph=True, allow_unused=True)
+        gd = torch.autograd.grad(d_loss, dp, allow_unused=True)
+        grads = {}
+        it = iter([torch.zeros_like(p) if g is None else g for g, p in zip(list(gg) + list(gd), gp + dp)])
+        for n in ("Gab", "Gba", "Da", "Db"):
+            grads[n] = {k: next(it) for k in P[n]}
+        self.t += 1
+        with torch.no_grad():
+            for n in P:
+                for k, p in P[n].items():
+                    adam_tf_(p, grads[n][k], self.m[n][k], self.v[n][k], self.t, self.lr, self.beta1)
+        return {"g_loss": g_loss.item(), "d_loss": d_loss.item(), "grads": grads,
+                "fake_B": fake_B.detach().permute(0, 2, 3, 1), "cyc_A": cyc_A.detach().permute(0, 2, 3, 1)}

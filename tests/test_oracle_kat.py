@@ -122,3 +122,30 @@ def test_oracle_vs_torch_full_step_small_net():
         PG, PD, st = r["PG"], r["PD"], r["opt_state"]
         for k in PG:
             assert np.abs(PG[k] - S.PG[k].detach().numpy()).max() < 1e-8, k
+
+
+def test_cycle_step_oracle_vs_torch():
+    """NumPy cycle_step vs the independent torch composition (float64, reduced networks), both GAN criteria."""
+    import torch
+    from oracle import torch_restatement as T
+    rng = np.random.default_rng(5)
+    gs = O.generator_param_shapes(gf_dim=8, n_blocks=1); ds = O.discriminator_param_shapes(df_dim=8)
+    P = {n: O.init_params(sh, rng, 0.1) for n, sh in (("Gab", gs), ("Gba", gs), ("Da", ds), ("Db", ds))}
+    N, H, W = 1, 256, 256
+    real_A, real_B = rng.uniform(0, 1, (N, H, W, 3)), rng.uniform(0, 1, (N, H, W, 3))
+    pal = rng.integers(0, 256, (8, 3)) / 255.0
+    seg_A = pal[np.repeat(np.repeat(rng.integers(0, 8, (N, 8, 8)), 32, 1), 32, 2)]
+    seg_B = pal[np.repeat(np.repeat(rng.integers(0, 8, (N, 8, 8)), 32, 1), 32, 2)]
+    mk = lambda: np.stack([O.one_hot(i, 34) for i in rng.integers(0, 34, (N, 5, 5))]).astype(float)
+    mask_A, mask_B = mk(), mk()
+    for lsgan in (True, False):
+        r = O.cycle_step(P["Gab"], P["Gba"], P["Da"], P["Db"], real_A, real_B, seg_A, seg_B, mask_A, mask_B, use_lsgan=lsgan, n_blocks=1)
+        o = T.CycleStep(P, torch.float64, use_lsgan=lsgan, n_blocks=1).step(real_A, real_B, seg_A, seg_B, mask_A, mask_B)
+        assert abs(r["g_loss"] - o["g_loss"]) < 1e-10 and abs(r["d_loss"] - o["d_loss"]) < 1e-10
+        assert np.abs(r["fake_B"] - o["fake_B"].numpy()).max() < 1e-10
+        for n in r["grads"]:
+            for k, g in r["grads"][n].items():
+                assert np.abs(g - o["grads"][n][k].numpy()).max() < 1e-8 * max(1, np.abs(g).max()), (lsgan, n, k)
+    # edge indicator: 1 exactly on the two columns next to a vertical class boundary
+    seg = np.zeros((1, 5, 6, 3)); seg[:, :, 3:] = 0.5
+    assert O.seg_edge_weight(seg)[0, :, :, 0].tolist() == [[0, 0, 1, 1, 0, 0]] * 5

@@ -210,7 +210,7 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with nproc-per-node {a.gpus} (WORLD_SIZE={world})")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: exercise the RCCL path even at N=1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -220,7 +220,7 @@ def main():
     def make_model(mode):
         m = sggan_amd.sggan(sggan_amd.default_args(dtype=a.dtype, device=f"cuda:{local}", image_height=a.height,
                                                    image_width=a.width, batch_size=a.batch, cycle=(mode == "cycle")))
-        if world > 1:
+        if dist is not None:
             m.enable_data_parallel()
         set_inputs(m, a.batch, a.height, a.width, 19 + rank)
         return m

@@ -337,22 +337,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 // -------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[4] = {0u, 0u, 0u, 0u};
 
-template <typename T, int MODE, int BM, int BN, int WGM, int NW>
+template <typename T, int MODE, int BM, int BN, int WGM, int NW, int BKB, int NS>
 __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
     constexpr int VEC = ET<T>::VEC;
     constexpr int ES = (int)sizeof(T);
     constexpr int WGN = NW / WGM;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / 16, NI = WN / 16;
-    constexpr int RPP = NW * 8;                 // tile rows staged per pass (one 1-KiB wave-instruction = 8 rows)
+    constexpr int CPR = BKB / 16;               // 16-byte chunks per LDS row (8: 128-byte K-slices, 4: 64-byte)
+    constexpr int RPW = 64 / CPR;               // tile rows per 1-KiB wave-instruction
+    constexpr int RPP = NW * RPW;               // tile rows staged per pass
     constexpr int PA = BM / RPP;
     constexpr int QA = (BN + RPP - 1) / RPP;
     constexpr int BNR = QA * RPP;               // weight-tile rows incl. padding
-    constexpr int STAGE = (BM + BNR) * 128;     // bytes per LDS stage
+    constexpr int STAGE = (BM + BNR) * BKB;     // bytes per LDS stage
+    constexpr int LPT = PA + QA;                // DMA instructions per thread per K-tile
+    constexpr int KK = BKB / 64;                // 32-element MFMA k-steps per K-tile
+    static_assert(BKB == 128 || BKB == 64, "row bytes");
+    static_assert(NS >= 2 && (NS - 2) * LPT <= 63, "stages / vmcnt range");
     static_assert(MODE == MODE_FWD || MODE == MODE_DGRAD, "mode");
     static_assert(BM % RPP == 0 && WM % 16 == 0 && WN % 16 == 0 && WGM * WGN == NW, "tile shape");
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages of { P [BM][128], Q [BNR][128] }
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NS stages of { P [BM][BKB], Q [BNR][BKB] }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -396,14 +402,19 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
         h = hbase + st * hp; w = wbase + st * (rem - hp * Wc);
     };
 
-    // staging rows of this thread: row = (tid>>3) + RPP*i at LDS position (tid&7); logical chunk = pos ^ swz(row)
-    const int lcc = (tid & 7) ^ ((tid >> 4) & 7);             // swz(row) = (row>>1)&7 = (tid>>4)&7 for every i
+    // swizzle key of a tile row: 128-byte rows: (row>>1)&7; 64-byte rows: (-(row>>2))&3  (both make every 16-lane
+    // ds_read_b128 group hit 16 distinct 16-byte slots of the 256-byte bank line)
+    auto swz = [](int row) { return CPR == 8 ? ((row >> 1) & 7) : ((-(row >> 2)) & 3); };
+    // staging rows of this thread: row = tid/CPR + RPP*i at LDS position tid%CPR; logical chunk = pos ^ swz(row),
+    // and swz(row) is the same for every pass i (RPP is a multiple of 16)
+    const int srow0 = tid / CPR;
+    const int lcc = (tid % CPR) ^ swz(srow0);
     int rn[PA], rh[PA], rw[PA];
     const bool fold = (MODE == MODE_DGRAD) && a.reflect;     // REFLECT data-gradient: MirrorPadGrad terms on the border
     unsigned bmask = 0;                                       // rows of this thread that receive mirrored terms
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        int m = m0 + (tid >> 3) + RPP * i;
+        int m = m0 + srow0 + RPP * i;
         if (m < M) {
             int n, h, w;
             decode(m, n, h, w);
@@ -437,83 +448,109 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
     }
 
     // split-K (a.ksplit > 1): blockIdx.y selects a contiguous range of K-tiles; partial sums go to f32 slabs
-    const int ktot = (nr * ns * cpv + 7) / 8;
+    const int ktot = (nr * ns * cpv + CPR - 1) / CPR;
     const int kper = (ktot + a.ksplit - 1) / a.ksplit;
     const int kt0 = (int)blockIdx.y * kper;
     const int ktiles = max(0, min(ktot, kt0 + kper) - kt0);
     int t_cc, t_ri, t_si;
-    { int q0 = lcc + kt0 * 8; int ti = q0 / cpv; t_cc = q0 - ti * cpv; t_ri = ns ? ti / ns : nr; t_si = ns ? ti - t_ri * ns : 0; }
+    { int q0 = lcc + kt0 * CPR; int ti = q0 / cpv; t_cc = q0 - ti * cpv; t_ri = ns ? ti / ns : nr; t_si = ns ? ti - t_ri * ns : 0; }
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
-    auto stage_tile = [&](int stg) {
-        char* sP = smem + stg * STAGE;
-        char* sQ = sP + BM * 128;
+    // Source addresses are kept per tap: the row/weight base pointers are rebuilt only when this thread's chunk
+    // column moves to another tap (every SC/(VEC*CPR) K-tiles); within a tap a K-tile costs one 64-bit add per DMA.
+    const char* pbase[PA];
+    const char* qbase[QA];
+    unsigned pok = 0, qok = 0;
+    bool tapchg = true;
+    auto rebuild = [&]() {
         const bool tapok = t_ri < nr;
         const int r = ph + st * t_ri, s = pw + st * t_si;
-        // ---- weights: always direct-to-LDS ----
+        pok = 0; qok = 0;
 #pragma unroll
         for (int i = 0; i < QA; ++i) {
-            int row = (tid >> 3) + RPP * i, dc = n0 + row;
-            const char* src = zero;
-            if (tapok && dc < DC) src = a.wmat + ((size_t)dc * wrow + (size_t)(r * a.S + s) * SC + t_cc * VEC) * ES;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sQ + (wave * 8 + RPP * i) * 128), 16, 0, 0);
+            int dc = n0 + srow0 + RPP * i;
+            qbase[i] = zero;
+            if (tapok && dc < DC) { qbase[i] = a.wmat + ((size_t)dc * wrow + (size_t)(r * a.S + s) * SC) * ES; qok |= 1u << i; }
         }
-        // ---- pixels: direct-to-LDS gather ----
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            const char* src = zero;
-            if (tapok && rn[i] >= 0) {
-                if (MODE == MODE_FWD) {
-                    int hi = rh[i] + r, wi = rw[i] + s;
-                    bool ok = true;
-                    if (a.reflect) {
-                        hi = hi < 0 ? -hi : (hi >= a.H ? 2 * (a.H - 1) - hi : hi);
-                        wi = wi < 0 ? -wi : (wi >= a.W ? 2 * (a.W - 1) - wi : wi);
-                    } else ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-                    if (ok) src = a.src + (((size_t)rn[i] * a.H + hi) * a.W + wi) * SC * ES + t_cc * 16;
-                } else if (fold && ((bmask >> i) & 1u)) {
-                    // MirrorPadGrad: border pixels gather from the side tensor, whose row (pixel, tap) already
-                    // holds the sum over the mirrored preimages (fold_gather_kernel)
-                    src = a.fold + ((size_t)rh[i] * (a.R * a.S) + (r * a.S + s)) * SC * ES + t_cc * 16;
-                } else {
-                    int ho = rh[i] - t_ri, wo = rw[i] - t_si;
-                    if ((unsigned)ho < (unsigned)a.Ho && (unsigned)wo < (unsigned)a.Wo)
-                        src = a.src + (((size_t)rn[i] * a.Ho + ho) * a.Wo + wo) * SC * ES + t_cc * 16;
+            pbase[i] = zero;
+            if (!tapok || rn[i] < 0) continue;
+            if (MODE == MODE_FWD) {
+                int hi = rh[i] + r, wi = rw[i] + s;
+                bool ok = true;
+                if (a.reflect) {
+                    hi = hi < 0 ? -hi : (hi >= a.H ? 2 * (a.H - 1) - hi : hi);
+                    wi = wi < 0 ? -wi : (wi >= a.W ? 2 * (a.W - 1) - wi : wi);
+                } else ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                if (ok) { pbase[i] = a.src + (((size_t)rn[i] * a.H + hi) * a.W + wi) * SC * ES; pok |= 1u << i; }
+            } else if (fold && ((bmask >> i) & 1u)) {
+                // MirrorPadGrad: border pixels gather from the side tensor, whose row (pixel, tap) already
+                // holds the sum over the mirrored preimages (fold_gather_kernel)
+                pbase[i] = a.fold + ((size_t)rh[i] * (a.R * a.S) + (r * a.S + s)) * SC * ES; pok |= 1u << i;
+            } else {
+                int ho = rh[i] - t_ri, wo = rw[i] - t_si;
+                if ((unsigned)ho < (unsigned)a.Ho && (unsigned)wo < (unsigned)a.Wo) {
+                    pbase[i] = a.src + (((size_t)rn[i] * a.Ho + ho) * a.Wo + wo) * SC * ES; pok |= 1u << i;
                 }
             }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sP + (wave * 8 + RPP * i) * 128), 16, 0, 0);
         }
-        t_cc += 8;
-        while (t_cc >= cpv) { t_cc -= cpv; if (++t_si == ns) { t_si = 0; ++t_ri; } }
     };
+    auto stage_tile = [&](int stg) {
+        char* sP = smem + stg * STAGE;
+        char* sQ = sP + BM * BKB;
+        if (tapchg) { rebuild(); tapchg = false; }
+        const int coff = t_cc * 16;
+#pragma unroll
+        for (int i = 0; i < QA; ++i) {
+            const char* src = qbase[i] + (((qok >> i) & 1u) ? coff : 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sQ + (wave * RPW + RPP * i) * BKB), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const char* src = pbase[i] + (((pok >> i) & 1u) ? coff : 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sP + (wave * RPW + RPP * i) * BKB), 16, 0, 0);
+        }
+        t_cc += CPR;
+        while (t_cc >= cpv) { t_cc -= cpv; tapchg = true; if (++t_si == ns) { t_si = 0; ++t_ri; } }
+    };
+
     f32x4 acc[NI][MI];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int frow = lane & 15, fq = lane >> 4, fsw = frow >> 1;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fswP = swz(wm * WM + frow), fswQ = swz(wn * WN + frow);   // tile bases are multiples of 16: key per lane
 
-    // 2-stage ring: the loads of tile t+1 are in flight (direct to LDS) while tile t is multiplied; one barrier per tile
-    if (ktiles > 0) stage_tile(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // NS-stage ring: NS-1 tiles are in flight by DMA while one is multiplied; counted vmcnt leaves NS-2 of them
+    // outstanding across the (raw) barrier -- a __syncthreads() there would drain the whole queue.
+    auto wait_tiles = [&](bool steady) {
+        if (steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < ktiles) stage_tile(t);
+    wait_tiles(ktiles >= NS - 1);
+    __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < ktiles; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < ktiles) stage_tile(cur ^ 1);
-        const char* bP = smem + cur * STAGE + (wm * WM + frow) * 128;
-        const char* bQ = smem + cur * STAGE + BM * 128 + (wn * WN + frow) * 128;
+        const int cur = kt % NS;
+        const bool refill = kt + NS - 1 < ktiles;
+        if (refill) stage_tile((kt + NS - 1) % NS);
+        const char* bP = smem + cur * STAGE + (wm * WM + frow) * BKB;
+        const char* bQ = smem + cur * STAGE + BM * BKB + (wn * WN + frow) * BKB;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int off = (((fq + 4 * kk) ^ fsw) << 4);
+        for (int kk = 0; kk < KK; ++kk) {
+            const int offP = (((fq + 4 * kk) ^ fswP) << 4), offQ = (((fq + 4 * kk) ^ fswQ) << 4);
             u32x4 fw[NI];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) fw[i] = ld16(bQ + i * 16 * 128 + off);
+            for (int i = 0; i < NI; ++i) fw[i] = ld16(bQ + i * 16 * BKB + offQ);
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
-                u32x4 fp = ld16(bP + j * 16 * 128 + off);
+                u32x4 fp = ld16(bP + j * 16 * BKB + offP);
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     if constexpr (sizeof(T) == 2) {
@@ -528,10 +565,20 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        wait_tiles(refill);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 
+    // bias of this lane's 4 output channels per channel tile, fetched once (a per-store load would put a full
+    // L2 round trip in front of every one of the NI*MI stores)
+    float bv[NI][4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int dc = n0 + wn * WN + i * 16 + fq * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[i][e] = (a.bias && a.ksplit <= 1 && dc < DC) ? a.bias[dc + e] : 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
         int m = m0 + wm * WM + j * 16 + frow;
@@ -554,10 +601,7 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
             }
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = acc[i][j][e] + (a.bias ? a.bias[dc + e] : 0.f);
-                v[e] = act_apply(t, a.act, a.leak);
-            }
+            for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[i][j][e] + bv[i][e], a.act, a.leak);
             T* o = reinterpret_cast<T*>(a.dst) + dpix * DC + dc;
             if constexpr (sizeof(T) == 2) {
                 bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
@@ -1100,8 +1144,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_glds_kernel(WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int Mrows = a.R * a.S * a.C;
-    const int m0 = blockIdx.x * BT, n0 = blockIdx.y * BT;
-    const int pbeg = blockIdx.z * a.pix_per_split;
+    // 1-D grid, XCD-aware: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous range of logical ids
+    // with the (tap-row tile, cout tile) index fastest, so all tiles that stream the SAME pixel range run on ONE XCD and
+    // x / dy are fetched from HBM once per split instead of once per tile (PMC: 14 % -> L2 hits; speed only).
+    const int tilesM = (Mrows + BT - 1) / BT, tilesN = (a.K + BT - 1) / BT, tiles = tilesM * tilesN;
+    int lid;
+    {
+        const int b = (int)blockIdx.x, nm = (int)gridDim.x;
+        const int q = nm >> 3, rr = nm & 7, xcd = b & 7;
+        lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
+    }
+    const int split = lid / tiles, tl = lid - split * tiles;
+    const int m0 = (tl / tilesN) * BT, n0 = (tl % tilesN) * BT;
+    const int pbeg = split * a.pix_per_split;
     const int pend = min(a.P, pbeg + a.pix_per_split);
 
     // this thread stages LDS position `pos` of rows prow0 + RPS*i; it holds logical chunk pos ^ key(row)
@@ -1217,7 +1272,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_glds_kernel(WgradArgs a) {
         __syncthreads();
     }
 
-    float* slab = a.ws + (size_t)blockIdx.z * Mrows * a.K;
+    float* slab = a.ws + (size_t)split * Mrows * a.K;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1343,11 +1398,11 @@ static int conv_ksplit(int64_t Mmax, int DC, int classes, int ktot_max) {
     return ks < 2 ? 1 : (int)ks;
 }
 
-template <typename T, int MODE, int BM, int BN, int WGM, int NW>
+template <typename T, int MODE, int BM, int BN, int WGM, int NW, int BKB = 128, int NS = 2>
 static int launch_glds_cfg(const ConvArgs& a, int64_t Mmax, int DC, int classes, hipStream_t s) {
-    constexpr int RPP = NW * 8;
-    constexpr size_t lds = 2 * (size_t)(BM + (BN + RPP - 1) / RPP * RPP) * 128;
-    auto kern = conv_gemm_glds_kernel<T, MODE, BM, BN, WGM, NW>;
+    constexpr int RPP = NW * (64 / (BKB / 16));
+    constexpr size_t lds = (size_t)NS * (size_t)(BM + (BN + RPP - 1) / RPP * RPP) * BKB;
+    auto kern = conv_gemm_glds_kernel<T, MODE, BM, BN, WGM, NW, BKB, NS>;
     static bool attr_done = false;
     if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
     const int64_t tilesN = (DC + BN - 1) / BN;
@@ -1381,8 +1436,17 @@ static int launch_gemm(const ConvArgs& a, hipStream_t s) {
     if constexpr (MODE != MODE_BORDER) {
         if (use_glds()) {
             // big square tiles (8 waves, 1 block per CU) when there is enough work to fill the chip with them
-            if (DC >= 256 && Mmax * ((DC + 255) / 256) >= 256 * 160) return launch_glds_cfg<T, MODE, 256, 256, 2, 8>(a, Mmax, DC, classes, s);
-            if (DC >= 128 && Mmax * ((DC + 127) / 128) >= 256 * 160) return launch_glds_cfg<T, MODE, 256, 128, 4, 8>(a, Mmax, DC, classes, s);
+            // A/B switch: SGG_GEMM_DEEP=1 selects 64-byte K-slices in a 4-stage ring (3 tiles in flight).  Measured
+            // on the residual conv (same box, interleaved): 2-stage 128-byte slices are 3-5 % faster, so they are
+            // the default -- the DMA latency is not what the waves wait for.
+            static int deep = -1;
+            if (deep < 0) { const char* e = getenv("SGG_GEMM_DEEP"); deep = (e && e[0] == '1') ? 1 : 0; }
+            if (DC >= 256 && Mmax * ((DC + 255) / 256) >= 256 * 160)
+                return deep ? launch_glds_cfg<T, MODE, 256, 256, 2, 8, 64, 4>(a, Mmax, DC, classes, s)
+                            : launch_glds_cfg<T, MODE, 256, 256, 2, 8, 128, 2>(a, Mmax, DC, classes, s);
+            if (DC >= 128 && Mmax * ((DC + 127) / 128) >= 256 * 160)
+                return deep ? launch_glds_cfg<T, MODE, 256, 128, 4, 8, 64, 4>(a, Mmax, DC, classes, s)
+                            : launch_glds_cfg<T, MODE, 256, 128, 4, 8, 128, 2>(a, Mmax, DC, classes, s);
             if (DC >= 128) return launch_glds_cfg<T, MODE, 128, 128, 2, 4>(a, Mmax, DC, classes, s);
             if (DC > 16) return launch_glds_cfg<T, MODE, 128, 64, 4, 4>(a, Mmax, DC, classes, s);
             return launch_glds_cfg<T, MODE, 256, 16, 4, 4>(a, Mmax, DC, classes, s);
@@ -1509,7 +1573,7 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
         auto kern = conv_wgrad_glds_kernel<T>;
         static bool attr_done = false;
         if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
-        dim3 grid((unsigned)((d->R * d->S * d->C + 255) / 256), (unsigned)((d->K + 255) / 256), (unsigned)splits);
+        dim3 grid((unsigned)(((d->R * d->S * d->C + 255) / 256) * ((d->K + 255) / 256) * splits));
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
         rc = sgg_check_launch();
     } else if (d->K >= 128) rc = launch_wgrad_cfg<T, 128, 128, 2>(a, splits, s);
@@ -1528,8 +1592,8 @@ extern "C" {
 int sgg_debug_occupancy(int* out, int cap) {
     int n = 0, v = 0;
     if (cap < 4) return SGG_EINVAL;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_gemm_glds_kernel<bf16, MODE_FWD, 256, 256, 2, 8>, 512, 131072); out[n++] = v;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_gemm_glds_kernel<bf16, MODE_DGRAD, 256, 256, 2, 8>, 512, 131072); out[n++] = v;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_gemm_glds_kernel<bf16, MODE_FWD, 256, 256, 2, 8, 64, 4>, 512, 131072); out[n++] = v;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_gemm_glds_kernel<bf16, MODE_DGRAD, 256, 256, 2, 8, 64, 4>, 512, 131072); out[n++] = v;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_gemm_kernel<bf16, MODE_FWD, 128, 128, 2>, 256, 65536); out[n++] = v;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_wgrad_kernel<bf16, 128, 128, 2>, 256, 32768); out[n++] = v;
     return n;

@@ -189,6 +189,21 @@ def cpu_baseline(H, W, seed, max_seconds=30.0):
             "gflops": step_gflop_per_image(H, W) / dt}
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on stdout when its communicator is created; the bench contract is ONE JSON line
+    on stdout, so file descriptor 1 is pointed at stderr while the process group / first collective come up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,7 +228,11 @@ def main():
     if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: exercise the RCCL path even at N=1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            warm = torch.zeros(1, device=f"cuda:{local}")
+            dist.all_reduce(warm)                     # creates the communicator (and prints the banner) now
+            torch.cuda.synchronize()
 
     import sggan_amd
     from sggan_amd import kernels as K

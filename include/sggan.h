@@ -170,6 +170,11 @@ int sgg_seg_class_table(uint32_t* keys_host, uint8_t* vals_host, int capacity);
 /* utils.py:158-165 + :197-199 (deviation D1): one-hot of the align-corners nearest resample of the
  * class-index map:  mask[n,i,j,c] = (idx[n, round(i*(H-1)/(oh-1)), round(j*(W-1)/(ow-1))] == c). */
 int sgg_onehot_resample(const uint8_t* idx, float* mask, int N, int H, int W, int oh, int ow, int n_classes, void* stream);
+/* ---- evaluation (next-row SURVEY 8(f)4): metric._fast_hist (metric.py:18-24) and scores_seg_fake (metric.py:71-77), bit exact
+ * hist[n_class*t + p] += 1 for pixels with 0 <= t,p < n_class (uint64 counts, caller zeroes);
+ * labels[i] = argmax_c uint8(255*x[i][c]) over the first C_real channels (first maximum wins). */
+int sgg_confusion_hist(const int32_t* label_true, const int32_t* label_pred, int64_t n, int n_class, uint64_t* hist, void* stream);
+int sgg_argmax_u8_labels(const void* x, int32_t* labels, int64_t P, int C_real, int Cpad, int dtype, void* stream);
 /* f32 [P][Cs] -> dtype [P][Cd] with zero fill (Cd >= Cs), and back (drops padded channels). */
 int sgg_pad_channels(const float* src, void* dst, int64_t P, int Cs, int Cd, int dtype, void* stream);
 int sgg_unpad_channels(const void* src, float* dst, int64_t P, int Cs, int Cd, int dtype, void* stream);

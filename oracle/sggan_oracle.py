@@ -712,3 +712,61 @@ def cycle_step(PGab, PGba, PDa, PDb, real_A, real_B, seg_A, seg_B, mask_A, mask_
             new[n][k], st[n]["m"][k], st[n]["v"][k] = adam_tf(P[k], G[n][k], opt_state[n]["m"][k], opt_state[n]["v"][k], t, lr, beta1)
     return {"fake_A": fake_A.v, "fake_B": fake_B.v, "cyc_A": cyc_A.v, "cyc_B": cyc_B.v, "g_loss": float(g_loss.v),
             "d_loss": float(d_loss.v), "grads": G, "params": new, "opt_state": st}
+
+
+# ----------------------------------------------------------------------------
+# next-row helpers: image pool, evaluation scores
+# ----------------------------------------------------------------------------
+
+class ImagePoolRef:
+    """utils.py:27-53 restated on NumPy arrays; ``rng.rand()`` replaces the module-level ``np.random.rand()``."""
+
+    def __init__(self, maxsize=50, rng=None):
+        self.maxsize, self.num_img, self.images = maxsize, 0, []
+        self.rng = rng if rng is not None else np.random
+
+    def __call__(self, image):
+        if self.maxsize <= 0:
+            return image
+        if self.num_img < self.maxsize:
+            self.images.append([np.array(t) for t in image])
+            self.num_img += 1
+            return image
+        if self.rng.rand() > 0.5:
+            idx = int(self.rng.rand() * self.maxsize)
+            tmp1, tmp3 = self.images[idx][0], self.images[idx][2]
+            self.images[idx][0], self.images[idx][2] = np.array(image[0]), np.array(image[2])
+            idx = int(self.rng.rand() * self.maxsize)
+            tmp2, tmp4 = self.images[idx][1], self.images[idx][3]
+            self.images[idx][1], self.images[idx][3] = np.array(image[1]), np.array(image[3])
+            return [tmp1, tmp2, tmp3, tmp4]
+        return image
+
+
+def fast_hist(label_true, label_pred, n_class):
+    """metric.py:18-24."""
+    mask = (label_true >= 0) & (label_true < n_class)
+    return np.bincount(n_class * label_true[mask].astype(int) + label_pred[mask], minlength=n_class ** 2).reshape(n_class, n_class)
+
+
+def scores(label_trues, label_preds, n_class):
+    """metric.py:27-47."""
+    hist = np.zeros((n_class, n_class))
+    for lt, lp in zip(label_trues, label_preds):
+        hist += fast_hist(lt.flatten(), lp.flatten(), n_class)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        acc = np.diag(hist).sum() / hist.sum()
+        acc_cls = np.nanmean(np.diag(hist) / hist.sum(axis=1))
+        iu = np.diag(hist) / (hist.sum(axis=1) + hist.sum(axis=0) - np.diag(hist))
+        valid = hist.sum(axis=1) > 0
+        mean_iu = np.nanmean(iu[valid])
+        freq = hist.sum(axis=1) / hist.sum()
+        fwavacc = (freq[freq > 0] * iu[freq > 0]).sum()
+    return {"Overall Acc": acc, "Mean Acc": acc_cls, "FreqW Acc": fwavacc, "Mean IoU": mean_iu, "Class IoU": dict(zip(range(n_class), iu))}
+
+
+def scores_seg_fake(seg_image, fake_img):
+    """metric.py:71-77 (fake_img already a NumPy array here)."""
+    gts = np.argmax((255 * seg_image).astype(np.uint8).transpose(0, 3, 2, 1), axis=1)
+    preds = np.argmax((255 * fake_img).astype(np.uint8).transpose(0, 3, 2, 1), axis=1)
+    return gts, preds

@@ -64,6 +64,8 @@ SIGNATURES = {
     "sgg_seg_class_map": (_i, [_vp, _i, _i64, _vp, _vp]),
     "sgg_seg_class_table": (_i, [_vp, _vp, _i]),
     "sgg_onehot_resample": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "sgg_confusion_hist": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
+    "sgg_argmax_u8_labels": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp]),
     "sgg_pad_channels": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp]),
     "sgg_unpad_channels": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp]),
 }

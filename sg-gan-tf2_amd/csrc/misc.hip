@@ -359,6 +359,28 @@ __global__ void unpad_channels_kernel(const T* src, float* dst, int64_t P, int C
     }
 }
 
+// ---------------------------------------------------------------- evaluation (metric.py:18-47,71-77): integer, bit exact
+// hist[n_class * t + p] += 1 for every pixel with 0 <= t < n_class   (_fast_hist, metric.py:18-24)
+__global__ __launch_bounds__(256) void confusion_hist_kernel(const int32_t* lt, const int32_t* lp, int64_t n, int n_class, unsigned long long* hist) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int t = lt[i], p = lp[i];
+        if (t >= 0 && t < n_class && p >= 0 && p < n_class) atomicAdd(&hist[(size_t)n_class * t + p], 1ull);
+    }
+}
+// label = argmax_c uint8(255 * x[c]) over the first C_real channels, first maximum wins (np.argmax), with numpy's
+// float -> uint8 cast on x86 (truncate to int32, keep the low 8 bits)   (scores_seg_fake, metric.py:71-77)
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_u8_kernel(const T* x, int32_t* out, int64_t P, int Cr, int Cp) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        int best = 0, bv = -1;
+        for (int c = 0; c < Cr; ++c) {
+            int v = (int)(255.f * (float)x[i * Cp + c]) & 0xff;
+            if (v > bv) { bv = v; best = c; }
+        }
+        out[i] = best;
+    }
+}
+
 static inline int grid_for(int64_t n, int cap = 4096) {
     int64_t b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -523,6 +545,20 @@ int sgg_onehot_resample(const uint8_t* idx, float* mask, int N, int H, int W, in
     if (!idx || !mask || N <= 0 || H <= 0 || W <= 0 || oh <= 0 || ow <= 0 || n_classes <= 0) return SGG_EINVAL;
     int64_t total = (int64_t)N * oh * ow * n_classes;
     hipLaunchKernelGGL(onehot_resample_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, idx, mask, N, H, W, oh, ow, n_classes);
+    return sgg_check_launch();
+}
+
+int sgg_confusion_hist(const int32_t* label_true, const int32_t* label_pred, int64_t n, int n_class, uint64_t* hist, void* stream) {
+    if (!label_true || !label_pred || !hist || n < 0 || n_class <= 0) return SGG_EINVAL;
+    if (n == 0) return SGG_OK;
+    hipLaunchKernelGGL(confusion_hist_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, label_true, label_pred, n, n_class, (unsigned long long*)hist);
+    return sgg_check_launch();
+}
+int sgg_argmax_u8_labels(const void* x, int32_t* labels, int64_t P, int C_real, int Cpad, int dtype, void* stream) {
+    if (!x || !labels || P <= 0 || C_real <= 0 || Cpad < C_real) return SGG_EINVAL;
+    if (dtype == SGG_BF16) hipLaunchKernelGGL(argmax_u8_kernel<bf16>, dim3(grid_for(P)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, labels, P, C_real, Cpad);
+    else if (dtype == SGG_F32) hipLaunchKernelGGL(argmax_u8_kernel<float>, dim3(grid_for(P)), dim3(256), 0, (hipStream_t)stream, (const float*)x, labels, P, C_real, Cpad);
+    else return SGG_EINVAL;
     return sgg_check_launch();
 }
 

@@ -16,6 +16,7 @@ import torch
 from . import _abi as A
 from . import kernels as K
 from .module import Discriminator, Generator
+from .utils import ImagePool
 
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32, "fp32": torch.float32,
            "float32": torch.float32, torch.bfloat16: torch.bfloat16, torch.float32: torch.float32}
@@ -75,6 +76,12 @@ class sggan(object):
         self.gen_loss, self.disc_loss = self._loss[0:1], self._loss[1:2]
         self._dp = None
         self._world = 1
+        self.dataset_dir = g("dataset_dir", "city")
+        # model.py:79 builds ImagePool(args.max_size) but the fork never calls it; it is used by the cycle step when
+        # use_pool is set (upstream SG-GAN behaviour: D sees a history of fakes)
+        self.pool = ImagePool(g("max_size", 50), rng=g("pool_rng", None))
+        self.use_pool = bool(g("use_pool", False))
+        self.gen_loss_metric, self.disc_loss_metric, self._metric_n = 0.0, 0.0, 0
 
     # ------------------------------------------------------------------ data parallel (new capability)
     def enable_data_parallel(self, process_group=None):
@@ -186,15 +193,26 @@ class sggan(object):
         d_fA, d_fB = e(fake_A), e(fake_B)                    # gradient-sensitive terms write, the rest accumulate
         K.gradloss(fake_A, rB, wB, C, gl, d_fA, lam=self.Lg_lambda, accumulate_loss=True)
         K.gradloss(fake_B, rA, wA, C, gl, d_fB, lam=self.Lg_lambda, accumulate_loss=True)
+        # the discriminators judge a HISTORY of fakes when the image pool is on (utils.py:27-53); the pool returns the
+        # current fakes until it is full, and then (p = 1/2) older ones, which need their own D forward
+        tDAs, tDBs, DA_fs, DB_fs = tDAf, tDBf, DA_fake, DB_fake
+        if self.use_pool:
+            sA, sB_, smB, smA = self.pool([fake_A, fake_B, mB, mA])       # fake_A is judged on mask_B, fake_B on mask_A
+            if sA is not fake_A:
+                DA_fs, tDAs = Da.forward(sA, smB)
+                dA_f = e(DA_fs)
+            if sB_ is not fake_B:
+                DB_fs, tDBs = Db.forward(sB_, smA)
+                dB_f = e(DB_fs)
         crit(DA_real, 1.0, dl, dA_r, weight=0.5)
-        crit(DA_fake, 0.0, dl, dA_f, weight=0.5, accumulate_loss=True)
+        crit(DA_fs, 0.0, dl, dA_f, weight=0.5, accumulate_loss=True)
         crit(DB_real, 1.0, dl, dB_r, weight=0.5, accumulate_loss=True)
-        crit(DB_fake, 0.0, dl, dB_f, weight=0.5, accumulate_loss=True)
+        crit(DB_fs, 0.0, dl, dB_f, weight=0.5, accumulate_loss=True)
 
         # discriminator gradients (fakes are constants here)
-        Da.backward(tDAr, dA_r); Da.backward(tDAf, dA_f)
+        Da.backward(tDAr, dA_r); Da.backward(tDAs, dA_f)
         hDa = self._allreduce(Da)
-        Db.backward(tDBr, dB_r); Db.backward(tDBf, dB_f)
+        Db.backward(tDBr, dB_r); Db.backward(tDBs, dB_f)
         hDb = self._allreduce(Db)
         # generator gradients: cycle terms first (they reach the other generator through the fakes)
         d_fB = K.add(d_fB, Gba.backward(t4, d_cycA, want_dx=True))
@@ -222,22 +240,84 @@ class sggan(object):
         return v[0], v[1]
 
     def state_dict(self):
-        G, D = self.generator.P, self.discriminator.P
-        return {"G": G.flat.cpu(), "D": D.flat.cpu(), "G_m": G.m.cpu(), "G_v": G.v.cpu(), "D_m": D.m.cpu(), "D_v": D.v.cpu(),
-                "G_t": G.step_count, "D_t": D.step_count}
+        sd = {}
+        names = ("G", "D", "G_BA", "D_B") if self.cycle else ("G", "D")
+        for key, net in zip(names, self.networks()):
+            P = net.P
+            sd[key] = {"flat": P.flat.cpu(), "m": P.m.cpu(), "v": P.v.cpu(), "t": P.step_count}
+        return sd
 
     def load_state_dict(self, sd):
-        for key, net in (("G", self.generator), ("D", self.discriminator)):
-            net.P.flat.copy_(sd[key]); net.P.m.copy_(sd[key + "_m"]); net.P.v.copy_(sd[key + "_v"])
-            net.P.step_count = int(sd[key + "_t"]); net.P.version += 1
+        names = ("G", "D", "G_BA", "D_B") if self.cycle else ("G", "D")
+        for key, net in zip(names, self.networks()):
+            P = net.P
+            P.flat.copy_(sd[key]["flat"]); P.m.copy_(sd[key]["m"]); P.v.copy_(sd[key]["v"])
+            P.step_count = int(sd[key]["t"]); P.version += 1
 
-    def save(self, path):
-        """model.py:450-468 saves weights only; the optimizer slots are added here so training can resume."""
-        torch.save(self.state_dict(), path)
+    def _ckpt_paths(self, checkpoint_dir, ep=None):
+        """model.py:454-456: <checkpoint_dir>/<dataset_dir>/{gen,disc}/cp-{epoch:04d}.ckpt"""
+        import os
+        base = os.path.join(checkpoint_dir, self.dataset_dir)
+        f = (lambda sub: os.path.join(base, sub, "cp-%04d.ckpt" % ep)) if ep is not None else (lambda sub: os.path.join(base, sub))
+        return f("gen"), f("disc")
 
-    def load(self, path):
-        self.load_state_dict(torch.load(path, map_location="cpu"))
+    def save(self, checkpoint_dir, ep):
+        """model.py:450-468 (weights per network under gen/ and disc/), plus what the reference omits: the Adam
+        slots and step counts, so training resumes exactly (SURVEY.md 5 "Checkpoint / resume")."""
+        import os
+        gpath, dpath = self._ckpt_paths(checkpoint_dir, ep)
+        sd = self.state_dict()
+        for path, keys in ((gpath, ("G", "G_BA")), (dpath, ("D", "D_B"))):
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            torch.save({k: sd[k] for k in keys if k in sd}, path)
+        return gpath, dpath
+
+    def load(self, checkpoint_dir):
+        """model.py:471-503: load the latest gen/disc checkpoints; False if either is missing."""
+        import glob
+        gdir, ddir = self._ckpt_paths(checkpoint_dir)
+        lg, ld = sorted(glob.glob(gdir + "/cp-*.ckpt")), sorted(glob.glob(ddir + "/cp-*.ckpt"))
+        if not (lg and ld):
+            return False
+        sd = {}
+        sd.update(torch.load(lg[-1], map_location="cpu"))
+        sd.update(torch.load(ld[-1], map_location="cpu"))
+        self.load_state_dict(sd)
         return True
+
+    def train(self, args, batches, log=print):
+        """The reference's epoch loop (model.py:202-275) around ``train_step`` for a caller-supplied batch source:
+        ``batches(epoch)`` yields dicts with real_A / seg_A / mask_A (+ real_B / seg_B / mask_B in cycle mode) --
+        disk loading and augmentation (utils.py:167-233) stay on the caller's side.  Prints the reference's line
+        (model.py:260), keeps its running-mean loss metrics (model.py:23-24,193-194,270-271), honours
+        --continue_train (model.py:210-215) and saves in ``finally`` like model.py:272-275."""
+        import time
+        start = time.time()
+        if getattr(args, "continue_train", False):
+            log(" [*] Loading pretrained weights ...")
+            log(" [*] Load SUCCESS" if self.load(args.checkpoint_dir) else " [!] Load failed...")
+        else:
+            log(" [*] New training STARTED")
+        history, epoch = [], 0
+        try:
+            for epoch in range(args.epoch):
+                self.gen_loss_metric = self.disc_loss_metric = 0.0
+                self._metric_n = 0
+                data = list(batches(epoch))
+                for idx, b in enumerate(data):
+                    for k, v in b.items():
+                        setattr(self, k, v)
+                    self.train_step(args)
+                    gl, dl = self.losses()
+                    self._metric_n += 1
+                    self.gen_loss_metric += (gl - self.gen_loss_metric) / self._metric_n
+                    self.disc_loss_metric += (dl - self.disc_loss_metric) / self._metric_n
+                    log("Epoch: [%2d] [%4d/%4d] time: %4.4f Gen_Loss: %f Disc_Loss: %f " % (epoch, idx, len(data), time.time() - start, gl, dl))
+                history.append({"epoch": epoch, "Generator Loss": self.gen_loss_metric, "Discriminator Loss": self.disc_loss_metric})
+        finally:
+            if getattr(args, "checkpoint_dir", None):
+                self.save(args.checkpoint_dir, epoch)
+        return history
 
 
 class _LazyUnpad:

@@ -1,0 +1,98 @@
+"""GPU tests of the rows SURVEY.md 8(f) marks "next": device-resident ImagePool, epoch loop + checkpoint/resume,
+evaluation scores.  Integer results are bit exact against the oracle's restatements."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sggan_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sg():
+    import sggan_amd
+    import sggan_amd.metric, sggan_amd.utils, sggan_amd.main  # noqa: F401,E401
+    return sggan_amd
+
+
+def test_image_pool_matches_reference_protocol(sg):
+    """Same decisions and same returned contents as utils.py:27-53 for the same random stream."""
+    rs1, rs2 = np.random.RandomState(3), np.random.RandomState(3)
+    pool = sg.utils.ImagePool(4, rng=rs1)
+    ref = O.ImagePoolRef(4, rng=rs2)
+    rng = np.random.default_rng(0)
+    for step in range(40):
+        arrs = [rng.standard_normal((1, 2, 2, 8)).astype(np.float32) for _ in range(2)] + [rng.standard_normal((1, 2, 2, 3)).astype(np.float32) for _ in range(2)]
+        out = pool([torch.as_tensor(a).cuda() for a in arrs])
+        exp = ref(arrs)
+        for o, e in zip(out, exp):
+            assert o.is_cuda and np.array_equal(o.cpu().numpy(), e), step
+    assert pool.num_img == ref.num_img == 4
+    img = [torch.zeros(1, device="cuda")] * 4
+    assert sg.utils.ImagePool(0)(img) is img                                       # maxsize <= 0: pass-through
+
+
+def test_scores_and_label_rule_bit_exact(sg):
+    M = sg.metric
+    rng = np.random.default_rng(4)
+    lt = rng.integers(-1, 9, (3, 64, 48)); lp = rng.integers(0, 8, (3, 64, 48))     # includes ignored labels (-1, 8)
+    assert np.array_equal(M._fast_hist(lt[0], lp[0], 8), O.fast_hist(lt[0].flatten(), lp[0].flatten(), 8))
+    got, exp = M.scores(list(lt), list(lp), 8), O.scores(list(lt), list(lp), 8)
+    for k in ("Overall Acc", "Mean Acc", "FreqW Acc", "Mean IoU"):
+        assert got[k] == exp[k], k
+    assert all((np.isnan(got["Class IoU"][c]) and np.isnan(exp["Class IoU"][c])) or got["Class IoU"][c] == exp["Class IoU"][c] for c in range(8))
+    seg = rng.uniform(0, 1, (2, 32, 16, 3)).astype(np.float32)
+    fake = np.tanh(rng.standard_normal((2, 32, 16, 3))).astype(np.float32)         # negative values: uint8 wrap-around
+    g, p = M.scores_seg_fake(seg, torch.as_tensor(fake))
+    eg, ep = O.scores_seg_fake(seg, fake)
+    assert g.shape == eg.shape == (2, 16, 32) and np.array_equal(g, eg) and np.array_equal(p, ep)
+
+
+def test_train_loop_checkpoint_resume(sg, tmp_path):
+    """model.train (model.py:202-275) + save/load (model.py:450-503): resuming from the checkpoint reproduces the
+    uninterrupted run bit for bit (the reference loses its Adam slots on reload; the build saves them)."""
+    argv = ["--epoch", "2", "--batch_size", "1", "--img_height", "128", "--img_width", "128", "--ngf", "8", "--ndf", "8",
+            "--dtype", "f32", "--steps_per_epoch", "2", "--checkpoint_dir", str(tmp_path / "ck"), "--dataset_dir", "unit"]
+    args = sg.main.build_parser().parse_args(argv)
+    args.use_resnet, args.n_blocks = True, 2
+    lines = []
+    m = sg.sggan(args)
+    hist = m.train(args, sg.main.synthetic_batches(m, args), log=lines.append)
+    assert len(hist) == 2 and all(np.isfinite(h["Generator Loss"]) for h in hist)
+    assert sum(l.startswith("Epoch: [") for l in lines) == 4 and " Gen_Loss: " in lines[1]
+    assert os.path.exists(tmp_path / "ck" / "unit" / "gen" / "cp-0001.ckpt") and os.path.exists(tmp_path / "ck" / "unit" / "disc" / "cp-0001.ckpt")
+    ref_G = m.generator.P.flat.clone()
+    # interrupted run: 1 epoch, save; new object, --continue_train, second epoch's batches
+    a1 = sg.main.build_parser().parse_args(argv); a1.use_resnet, a1.n_blocks, a1.epoch, a1.checkpoint_dir = True, 2, 1, str(tmp_path / "ck2")
+    m1 = sg.sggan(a1)
+    m1.train(a1, sg.main.synthetic_batches(m1, a1), log=lambda s: None)
+    a2 = sg.main.build_parser().parse_args(argv); a2.use_resnet, a2.n_blocks, a2.epoch, a2.checkpoint_dir, a2.continue_train = True, 2, 1, str(tmp_path / "ck2"), True
+    m2 = sg.sggan(a2)
+    second = sg.main.synthetic_batches(m2, a2)
+    m2.train(a2, lambda ep: second(1), log=lambda s: None)
+    assert m2.generator.P.step_count == 4 and torch.equal(m2.generator.P.flat, ref_G)
+
+
+def test_cycle_step_with_image_pool(sg):
+    """use_pool: D is trained on the pool's history; before the pool fills it is the current fakes (identical step)."""
+    def run(use_pool):
+        m = sg.sggan(sg.default_args(ngf=8, ndf=8, n_blocks=1, dtype="f32", cycle=True, use_pool=use_pool, max_size=2,
+                                     pool_rng=np.random.RandomState(0)))
+        g = torch.Generator().manual_seed(1)
+        outs = []
+        for _ in range(5):
+            m.real_A, m.real_B = torch.rand((1, 256, 256, 3), generator=g), torch.rand((1, 256, 256, 3), generator=g)
+            m.seg_A, m.seg_B = torch.rand((1, 256, 256, 3), generator=g), torch.rand((1, 256, 256, 3), generator=g)
+            mk = lambda: torch.nn.functional.one_hot(torch.randint(0, 34, (1, 5, 5), generator=g), 34).float()
+            m.mask_A, m.mask_B = mk(), mk()
+            m.train_step()
+            outs.append(m.losses())
+        return m, outs
+    m0, o0 = run(False)
+    m1, o1 = run(True)
+    assert o0[0] == o1[0] and o0[1] == o1[1]                  # pool not yet full: same losses
+    assert m1.pool.num_img == 2 and all(np.isfinite(v) for pair in o1 for v in pair)
+    assert o0 != o1                                           # after it fills, D sees older fakes at least once

@@ -33,6 +33,7 @@ struct ConvArgs {
     const char* fold;    // REFLECT DGRAD (v2): pre-folded gather rows of the border pixels [pixel][tap][K], else nullptr
     float* partial;      // split-K (v2): f32 slabs [ksplit][pdst][DC]
     int ksplit;          // 1 = no split
+    int ablate;          // timing experiments only (SGG_ABLATE): 1 skips the in-loop DMA, 2 skips the LDS reads + MFMAs
     size_t pdst;         // destination pixels (slab stride)
     int N, H, W, C, K, R, S, stride, pad_t, pad_l, Ho, Wo, reflect;
     int act;
@@ -539,30 +540,48 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
     for (int kt = 0; kt < ktiles; ++kt) {
         const int cur = kt % NS;
         const bool refill = kt + NS - 1 < ktiles;
-        if (refill) stage_tile((kt + NS - 1) % NS);
+        if (refill && a.ablate != 1) stage_tile((kt + NS - 1) % NS);
         const char* bP = smem + cur * STAGE + (wm * WM + frow) * BKB;
         const char* bQ = smem + cur * STAGE + BM * BKB + (wn * WN + frow) * BKB;
+        if (a.ablate != 2) {
+            // Fragment pipeline: all weight fragments of the tile up front, pixel fragments in groups of GJ that are
+            // fetched one group ahead of the MFMAs that consume them, so the ~100-cycle LDS latency hides behind
+            // GJ*NI MFMAs instead of stalling every 8 (what hipcc emitted for the plain j-loop).
+            constexpr int GJ = MI >= 4 ? 4 : MI;             // pixel fragments per group
+            constexpr int GPK = MI / GJ;                      // groups per k-step
+            constexpr int NG = KK * GPK;
+            u32x4 fw[KK][NI];
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            const int offP = (((fq + 4 * kk) ^ fswP) << 4), offQ = (((fq + 4 * kk) ^ fswQ) << 4);
-            u32x4 fw[NI];
+            for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-            for (int i = 0; i < NI; ++i) fw[i] = ld16(bQ + i * 16 * BKB + offQ);
+                for (int i = 0; i < NI; ++i) fw[kk][i] = ld16(bQ + i * 16 * BKB + (((fq + 4 * kk) ^ fswQ) << 4));
+            u32x4 fp[2][GJ];
 #pragma unroll
-            for (int j = 0; j < MI; ++j) {
-                u32x4 fp = ld16(bP + j * 16 * BKB + offP);
+            for (int jj = 0; jj < GJ; ++jj) fp[0][jj] = ld16(bP + jj * 16 * BKB + ((fq ^ fswP) << 4));
 #pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    if constexpr (sizeof(T) == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, fw[i]), __builtin_bit_cast(bf16x8, fp), acc[i][j], 0, 0, 0);
-                    } else {
+            for (int g = 0; g < NG; ++g) {
+                const int kk = g / GPK, jb = (g % GPK) * GJ;
+                if (g + 1 < NG) {
+                    const int kn = (g + 1) / GPK, jn = ((g + 1) % GPK) * GJ;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                __uint_as_float(fw[i][e]), __uint_as_float(fp[e]), acc[i][j], 0, 0, 0);
-                    }
+                    for (int jj = 0; jj < GJ; ++jj)
+                        fp[(g + 1) & 1][jj] = ld16(bP + (jn + jj) * 16 * BKB + (((fq + 4 * kn) ^ fswP) << 4));
                 }
+                __builtin_amdgcn_sched_barrier(0);           // keep the prefetch ABOVE this group's MFMAs
+#pragma unroll
+                for (int jj = 0; jj < GJ; ++jj)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        if constexpr (sizeof(T) == 2) {
+                            acc[i][jb + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, fw[kk][i]), __builtin_bit_cast(bf16x8, fp[g & 1][jj]), acc[i][jb + jj], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc[i][jb + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                    __uint_as_float(fw[kk][i][e]), __uint_as_float(fp[g & 1][jj][e]), acc[i][jb + jj], 0, 0, 0);
+                        }
+                    }
             }
         }
         wait_tiles(refill);
@@ -1352,6 +1371,7 @@ static bool desc_ok(const sgg_conv_desc* d) {
 static ConvArgs make_args(const sgg_conv_desc* d, const void* src, const void* w, const float* bias, void* dst, int act, float leak) {
     ConvArgs a;
     a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst; a.fold = nullptr; a.partial = nullptr; a.ksplit = 1; a.pdst = 0;
+    { static int ab = -1; if (ab < 0) { const char* e = getenv("SGG_ABLATE"); ab = e ? atoi(e) : 0; } a.ablate = ab; }
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S; a.stride = d->stride;
     a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.reflect = d->pad_mode == SGG_PAD_REFLECT;
     a.act = act; a.leak = leak;
@@ -1440,10 +1460,12 @@ static int launch_gemm(const ConvArgs& a, hipStream_t s) {
             // on the residual conv (same box, interleaved): 2-stage 128-byte slices are 3-5 % faster, so they are
             // the default -- the DMA latency is not what the waves wait for.
             static int deep = -1;
-            if (deep < 0) { const char* e = getenv("SGG_GEMM_DEEP"); deep = (e && e[0] == '1') ? 1 : 0; }
-            if (DC >= 256 && Mmax * ((DC + 255) / 256) >= 256 * 160)
+            if (deep < 0) { const char* e = getenv("SGG_GEMM_DEEP"); deep = e ? atoi(e) : 0; }
+            if (DC >= 256 && Mmax * ((DC + 255) / 256) >= 256 * 160) {
+                if (deep == 2) return launch_glds_cfg<T, MODE, 256, 256, 4, 16, 128, 2>(a, Mmax, DC, classes, s);   // 16 waves
                 return deep ? launch_glds_cfg<T, MODE, 256, 256, 2, 8, 64, 4>(a, Mmax, DC, classes, s)
                             : launch_glds_cfg<T, MODE, 256, 256, 2, 8, 128, 2>(a, Mmax, DC, classes, s);
+            }
             if (DC >= 128 && Mmax * ((DC + 127) / 128) >= 256 * 160)
                 return deep ? launch_glds_cfg<T, MODE, 256, 128, 4, 8, 64, 4>(a, Mmax, DC, classes, s)
                             : launch_glds_cfg<T, MODE, 256, 128, 4, 8, 128, 2>(a, Mmax, DC, classes, s);

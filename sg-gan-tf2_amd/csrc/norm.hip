@@ -8,20 +8,25 @@
 // Algorithmic bytes: fwd 2 reads + 1 write of the tensor, bwd 4 reads + 1 write.
 #include "common.h"
 
-#define IN_ROWS_PER_CHUNK 64         // pixels per partial-sum chunk
-
+// pixels per partial-sum chunk: >= 64, and large enough that an image has at most ~128 chunks (the finalize kernels
+// walk the chunks of one channel serially: 2048 chunks cost 68 us on a 256x512x64 tensor, 128 chunks 5 us)
+static inline int in_rows_per_chunk(int64_t HW) {
+    int64_t r = (HW + 127) / 128;
+    r = (r + 63) / 64 * 64;
+    return (int)(r < 64 ? 64 : (r > 4096 ? 4096 : r));
+}
 // ws layout: partial[N][chunks][C][2] f32, then sums[N][C][2] and tot[N][C][2] f32 (bwd only)
-static inline int in_chunks(int64_t HW) { return (int)((HW + IN_ROWS_PER_CHUNK - 1) / IN_ROWS_PER_CHUNK); }
+static inline int in_chunks(int64_t HW) { int r = in_rows_per_chunk(HW); return (int)((HW + r - 1) / r); }
 
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void in_partial_kernel(const char* x, const char* dy, const float* gamma, const float* beta,
                                                          const float* stats, float* partial, int64_t HW, int C, int chunks,
-                                                         int act, float leak) {
+                                                         int rpc, int act, float leak) {
     constexpr int VEC = ET<T>::VEC;
     const int CV = C / VEC;                       // channel vectors per pixel
     const int n = blockIdx.y, chunk = blockIdx.x;
-    const int64_t p0 = (int64_t)chunk * IN_ROWS_PER_CHUNK;
-    const int64_t p1 = p0 + IN_ROWS_PER_CHUNK < HW ? p0 + IN_ROWS_PER_CHUNK : HW;
+    const int64_t p0 = (int64_t)chunk * rpc;
+    const int64_t p1 = p0 + rpc < HW ? p0 + rpc : HW;
     __shared__ float red[256][2 * VEC + 1];
     // threads cover (pixel row, channel vector) pairs: cv = item % CV walks fastest
     for (int cvb = 0; cvb < CV; cvb += 256) {
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256) void in_finalize_bwd_kernel(const float* parti
     }
 }
 
-// dgamma[c] (+)= sum_n sum g*xhat ; dbeta[c] (+)= sum_n sum g
+// dgamma[c] (+)= sum_n sum g*xhat ; dbeta[c] (+)= sum_n sum g   (fixed order over n -> deterministic)
 __global__ void in_param_grad_kernel(const float* tot, float* dgamma, float* dbeta, int C, int N, int Cr, int accumulate) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= Cr) return;
@@ -208,11 +213,11 @@ int sgg_instnorm_fwd(const void* x, const float* gamma, const float* beta, const
     int rpb = in_rows_per_block(N, HW, C, 0);
     dim3 gp(chunks, N), ga((unsigned)((HW + rpb - 1) / rpb), N);
     if (dtype == SGG_BF16) {
-        hipLaunchKernelGGL((in_partial_kernel<bf16, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, act, leak);
+        hipLaunchKernelGGL((in_partial_kernel<bf16, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
         hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, stats, HW, C, chunks, eps);
         hipLaunchKernelGGL((in_apply_kernel<bf16, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak);
     } else if (dtype == SGG_F32) {
-        hipLaunchKernelGGL((in_partial_kernel<float, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, act, leak);
+        hipLaunchKernelGGL((in_partial_kernel<float, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
         hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, stats, HW, C, chunks, eps);
         hipLaunchKernelGGL((in_apply_kernel<float, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak);
     } else return SGG_EINVAL;
@@ -233,14 +238,14 @@ int sgg_instnorm_bwd(const void* dy, const void* x, const float* gamma, const fl
     int rpb = in_rows_per_block(N, HW, C, 0);
     dim3 gp(chunks, N), ga((unsigned)((HW + rpb - 1) / rpb), N);
     if (dtype == SGG_BF16) {
-        hipLaunchKernelGGL((in_partial_kernel<bf16, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, act, leak);
+        hipLaunchKernelGGL((in_partial_kernel<bf16, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
         hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, sums, tot, HW, C, chunks);
-        hipLaunchKernelGGL(in_param_grad_kernel, dim3((C_real + 255) / 256), dim3(256), 0, s, (const float*)tot, dgamma, dbeta, C, N, C_real, accumulate);
+        hipLaunchKernelGGL(in_param_grad_kernel, dim3((C_real + 63) / 64), dim3(64), 0, s, (const float*)tot, dgamma, dbeta, C, N, C_real, accumulate);
         hipLaunchKernelGGL((in_apply_kernel<bf16, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak);
     } else if (dtype == SGG_F32) {
-        hipLaunchKernelGGL((in_partial_kernel<float, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, act, leak);
+        hipLaunchKernelGGL((in_partial_kernel<float, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
         hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, sums, tot, HW, C, chunks);
-        hipLaunchKernelGGL(in_param_grad_kernel, dim3((C_real + 255) / 256), dim3(256), 0, s, (const float*)tot, dgamma, dbeta, C, N, C_real, accumulate);
+        hipLaunchKernelGGL(in_param_grad_kernel, dim3((C_real + 63) / 64), dim3(64), 0, s, (const float*)tot, dgamma, dbeta, C, N, C_real, accumulate);
         hipLaunchKernelGGL((in_apply_kernel<float, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak);
     } else return SGG_EINVAL;
     return sgg_check_launch();

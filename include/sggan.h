@@ -73,7 +73,9 @@ int sgg_conv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w_fwd, con
 /* bwd_data: dx = conv^T(dy) including the MirrorPadGrad fold for REFLECT (gen_tape.gradient, model.py:196).
  * ws: sgg_conv2d_bwd_data_workspace() bytes (REFLECT: pre-folded gather rows of the border pixels; small outputs: split-K slabs). */
 size_t sgg_conv2d_bwd_data_workspace(const sgg_conv_desc* d);
-int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
+/* addend (nullable, same shape/dtype as dx): dx = conv^T(dy) + addend -- the skip-connection gradient of a
+ * residual block (module.py:217) folded into the epilogue. */
+int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w_dgrad, const void* addend, void* dx,
                         void* ws, size_t ws_bytes, void* stream);
 /* bwd_weight: dw_hwio[R][S][C_real][K_real] f32, overwritten (accumulate=0) or added to (accumulate=1: a network
  * applied twice in one step, model.py:186-187).  ws: sgg_conv2d_bwd_weight_workspace() bytes. */

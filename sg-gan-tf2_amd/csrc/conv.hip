@@ -30,6 +30,7 @@ struct ConvArgs {
     const char* wmat;    // FWD: [K][R*S*C]     DGRAD: [C][R*S*K]
     const float* bias;   // per destination channel or nullptr
     char* dst;           // FWD: y (N,Ho,Wo,K)  DGRAD: dx (N,H,W,C)
+    const char* addend;  // optional tensor added to the result (same layout as dst): the skip-connection gradient
     const char* fold;    // REFLECT DGRAD (v2): pre-folded gather rows of the border pixels [pixel][tap][K], else nullptr
     float* partial;      // split-K (v2): f32 slabs [ksplit][pdst][DC]
     int ksplit;          // 1 = no split
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     float t = acc[i][j][e] + (a.bias ? a.bias[dc + e] : 0.f);
                     v[e] = act_apply(t, a.act, a.leak);
+                    if (a.addend) v[e] += (float)(reinterpret_cast<const T*>(a.addend) + dpix * DC + dc)[e];
                 }
             }
             if constexpr (sizeof(T) == 2) {
@@ -621,6 +623,11 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[i][j][e] + bv[i][e], a.act, a.leak);
+            if (a.addend) {                                      // + skip-connection gradient (module.py:217 backward)
+                const T* ad = reinterpret_cast<const T*>(a.addend) + dpix * DC + dc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)ad[e];
+            }
             T* o = reinterpret_cast<T*>(a.dst) + dpix * DC + dc;
             if constexpr (sizeof(T) == 2) {
                 bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
@@ -1370,7 +1377,7 @@ static bool desc_ok(const sgg_conv_desc* d) {
 
 static ConvArgs make_args(const sgg_conv_desc* d, const void* src, const void* w, const float* bias, void* dst, int act, float leak) {
     ConvArgs a;
-    a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst; a.fold = nullptr; a.partial = nullptr; a.ksplit = 1; a.pdst = 0;
+    a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst; a.addend = nullptr; a.fold = nullptr; a.partial = nullptr; a.ksplit = 1; a.pdst = 0;
     { static int ab = -1; if (ab < 0) { const char* e = getenv("SGG_ABLATE"); ab = e ? atoi(e) : 0; } a.ablate = ab; }
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S; a.stride = d->stride;
     a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.reflect = d->pad_mode == SGG_PAD_REFLECT;
@@ -1391,8 +1398,8 @@ static int launch_gemm_cfg(const ConvArgs& a, int64_t Mmax, int DC, int classes,
 
 // out[p][c] = act(sum_s partial[s][p][c] + bias[c])  (fixed order -> deterministic)
 template <typename T>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial, const float* bias, char* out, int64_t nvec4, int DC,
-                                                            int ksplit, size_t slab, int act, float leak) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial, const float* bias, const char* addend, char* out, int64_t nvec4,
+                                                            int DC, int ksplit, size_t slab, int act, float leak) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec4; i += (int64_t)gridDim.x * blockDim.x) {
         f32x4 s4 = *reinterpret_cast<const f32x4*>(partial + i * 4);
         for (int sp = 1; sp < ksplit; ++sp) s4 += *reinterpret_cast<const f32x4*>(partial + sp * slab + i * 4);
@@ -1400,6 +1407,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_apply(s4[e] + (bias ? bias[c + e] : 0.f), act, leak);
+        if (addend) {
+            const T* ad = reinterpret_cast<const T*>(addend) + i * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)ad[e];
+        }
         if constexpr (sizeof(T) == 2) {
             bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
             *reinterpret_cast<bf16x4*>(out + i * 8) = pk;
@@ -1515,7 +1527,7 @@ static int run_gemm(const sgg_conv_desc* d, ConvArgs a, void* ws, size_t ws_byte
     if (rc || g.ksplit <= 1) return rc;
     int64_t nvec4 = (int64_t)g.pdst * g.DC / 4;
     int blocks = (int)((nvec4 + 255) / 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, s, (const float*)ws, a.bias, a.dst, nvec4, g.DC, g.ksplit,
+    hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, s, (const float*)ws, a.bias, a.addend, a.dst, nvec4, g.DC, g.ksplit,
                        g.pdst * g.DC, a.act, a.leak);
     return sgg_check_launch();
 }
@@ -1656,9 +1668,10 @@ size_t sgg_conv2d_bwd_data_workspace(const sgg_conv_desc* d) {
     return fold_bytes(d) + plan_gemm(d, MODE_DGRAD).ws_bytes;
 }
 
-int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w, void* dx, void* ws, size_t ws_bytes, void* stream) {
+int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w, const void* addend, void* dx, void* ws, size_t ws_bytes, void* stream) {
     if (!desc_ok(d) || !dy || !w || !dx) return SGG_EINVAL;
     ConvArgs a = make_args(d, dy, w, nullptr, dx, SGG_ACT_NONE, 0.f);
+    a.addend = (const char*)addend;
     const size_t fb = fold_bytes(d);
     if (fb) {
         // v2: pre-fold the gather rows of the border pixels, then ONE GEMM launch reads them like any other source

@@ -140,13 +140,15 @@ def conv_fwd(g: ConvGeom, x, w_fwd, bias, act=A.ACT_NONE, leak=0.0):
     return y
 
 
-def conv_dgrad(g: ConvGeom, dy, w_dgrad):
+def conv_dgrad(g: ConvGeom, dy, w_dgrad, addend=None):
+    """dx = conv^T(dy) (+ addend: the skip-connection gradient, fused into the epilogue)."""
     assert tuple(dy.shape) == g.y_shape and not g.is_deconv
+    assert addend is None or (tuple(addend.shape) == g.x_shape and addend.dtype == dy.dtype)
     dx = torch.empty(g.x_shape, dtype=dy.dtype, device=dy.device)
     pr = _prof("conv2d_bwd_data", g)
     if pr: pr.start()
     ws = workspace(g.ws_dgrad, dy.device) if g.ws_dgrad else None
-    A.check(A.lib().sgg_conv2d_bwd_data(C.byref(g.desc), _p(dy), _p(w_dgrad), _p(dx), _p(ws), g.ws_dgrad, _s()), "conv2d_bwd_data")
+    A.check(A.lib().sgg_conv2d_bwd_data(C.byref(g.desc), _p(dy), _p(w_dgrad), _p(addend), _p(dx), _p(ws), g.ws_dgrad, _s()), "conv2d_bwd_data")
     if pr: pr.stop()
     return dx
 

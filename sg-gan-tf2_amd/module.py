@@ -204,7 +204,7 @@ class _ConvUnit:
         y, stats = K.instnorm_fwd(xc, P.p(n + "_g"), P.p(n + "_beta"), residual, self.net.eps, self.act, self.leak)
         return y, (g, x, xc, stats)
 
-    def backward(self, rec, dy, want_dx=True, param_grads=True, gbuf=None):
+    def backward(self, rec, dy, want_dx=True, param_grads=True, gbuf=None, addend=None):
         P, n = self.net.P, self.name
         g, x, xc, stats = rec
         wf, wd = self.packed(x.dtype)
@@ -223,7 +223,10 @@ class _ConvUnit:
             (K.conv_wgrad if self.kind == "conv" else K.deconv_wgrad)(g, x, dxc, P.g(n + "_w", buf=gbuf), accumulate=True)
         if not want_dx:
             return None
-        return K.conv_dgrad(g, dxc, wd) if self.kind == "conv" else K.deconv_dgrad(g, dxc, wf)
+        if self.kind == "conv":
+            return K.conv_dgrad(g, dxc, wd, addend)
+        dx = K.deconv_dgrad(g, dxc, wf)
+        return dx if addend is None else K.add(dx, addend)
 
 
 class _Net:
@@ -305,8 +308,7 @@ class Generator(_Net):
             d = u.backward(r, d, True, param_grads, gbuf)
         for (ua, ub), (ra, rb) in zip(reversed(self.blocks), reversed(tape[3:3 + nb])):
             t = ub.backward(rb, d, True, param_grads, gbuf)
-            t = ua.backward(ra, t, True, param_grads, gbuf)
-            d = K.add(t, d)                                   # gradient of the skip connection
+            d = ua.backward(ra, t, True, param_grads, gbuf, addend=d)   # + gradient of the skip connection (fused)
         d = self.c3.backward(tape[2], d, True, param_grads, gbuf)
         d = self.c2.backward(tape[1], d, True, param_grads, gbuf)
         return self.c1.backward(tape[0], d, want_dx, param_grads, gbuf)

@@ -1474,7 +1474,6 @@ static int launch_gemm(const ConvArgs& a, hipStream_t s) {
             static int deep = -1;
             if (deep < 0) { const char* e = getenv("SGG_GEMM_DEEP"); deep = e ? atoi(e) : 0; }
             if (DC >= 256 && Mmax * ((DC + 255) / 256) >= 256 * 160) {
-                if (deep == 2) return launch_glds_cfg<T, MODE, 256, 256, 4, 16, 128, 2>(a, Mmax, DC, classes, s);   // 16 waves
                 return deep ? launch_glds_cfg<T, MODE, 256, 256, 2, 8, 64, 4>(a, Mmax, DC, classes, s)
                             : launch_glds_cfg<T, MODE, 256, 256, 2, 8, 128, 2>(a, Mmax, DC, classes, s);
             }

@@ -243,3 +243,23 @@ def test_cycle_step_small_f32_matches_oracle(sg):
                 # Adam's first step is -lr*sign(g): elements whose gradient is at rounding-noise level may flip
                 sig = np.abs(ge) > 1e-3 * np.abs(ge).max()
                 assert np.abs(new[k] - e)[sig].max() < 2e-5, (n, k)
+
+
+@pytest.mark.parametrize("cfg", [("config2: 256x256, batch 4, bf16, cycle step", 4, 256, 256, True),
+                                 ("config5 shape: 1024x512, batch 2 per GPU, bf16, reference step", 2, 512, 1024, False),
+                                 ("odd sizes: 144x208 (not multiples of the tile sizes), f32-free bf16 cycle", 1, 144, 208, True)],
+                         ids=["cfg2", "cfg5", "odd"])
+def test_other_baseline_configs_run(sg, cfg):
+    """BASELINE.json configs[1] and configs[4] (per-GPU share) and a shape that exercises every tail path: one step,
+    finite losses, correct shapes, tanh-bounded images.  (1024x512 needs no activation checkpointing in 288 GB:
+    saved activations are ~2.5 GB per generator pass.)"""
+    _, N, H, W, cycle = cfg
+    m = sg.sggan(sg.default_args(dtype="bf16", cycle=cycle))
+    m.real_A, m.seg_A, m.mask_A = _rand_inputs(N, H, W, m.discriminator, 11)
+    if cycle:
+        m.real_B, m.seg_B, m.mask_B = _rand_inputs(N, H, W, m.discriminator, 12)
+    m.train_step()
+    gl, dl = m.losses()
+    assert np.isfinite(gl) and np.isfinite(dl), (gl, dl)
+    f = m.fake_A.numpy()
+    assert f.shape == (N, H, W, 3) and np.isfinite(f).all() and np.abs(f).max() <= 1.0

@@ -921,6 +921,133 @@ static int halo_wgrad_blocks(const sgg_conv_desc* d) {
     return ntiles < 256 ? ntiles : 256;
 }
 
+// Narrow-INPUT convolution (8 source channels = one 16-byte chunk per pixel, 64 output channels, stride 1, same-size):
+// the generator stem 7x7 3(8)->64 forward (module.py:230-232) and the data-gradient of the head 7x7 64->3(8).  As an
+// implicit GEMM every (pixel, tap) is a separate 16-byte DMA element; here the source halo of a 16x32 tile (13 KB) and
+// the whole weight matrix (64 x 49*8, 53 KB) sit in LDS, each lane picks the chunk of ITS tap out of the halo, and
+// persistent blocks amortise the weight load.  flip = data-gradient (taps mirrored, zero fill).
+template <typename T>
+__global__ __launch_bounds__(512) void conv_halo_narrow_in_kernel(ConvArgs a, int ntiles, int flip) {
+    constexpr int VEC = ET<T>::VEC;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int SCH = 8;                              // source channels
+    constexpr int CPV = SCH / VEC;                      // 16-byte chunks per (pixel, tap): 1 bf16, 2 f32
+    constexpr int PXB = SCH * ES;                       // bytes per halo pixel
+    constexpr int DCH = 64;                             // destination channels
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int taps = a.R * a.S;
+    const int kch = taps * CPV;                         // real 16-byte chunks per weight row
+    const int ksteps = (kch + 3) / 4;
+    const int wpitch = ((ksteps * 4) | 1) * 16;         // odd chunk count per row: conflict-free fragment reads
+    char* sW = smem;                                    // [64][wpitch]
+    char* sH = smem + DCH * wpitch;                     // halo [(TH+R-1)*(TW+S-1)][PXB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HWd = HALO_TW + a.S - 1, HHd = HALO_TH + a.R - 1, HP = HHd * HWd;
+    const int tilesW = a.W / HALO_TW, tilesH = a.H / HALO_TH;
+    const int frow = lane & 15, fq = lane >> 4;
+
+    // weights: rows = destination channels, zero beyond the real K
+    for (int idx = tid; idx < DCH * ksteps * 4; idx += 512) {
+        int row = idx / (ksteps * 4), ch = idx - row * (ksteps * 4);
+        u32x4 v = zero16();
+        if (ch < kch) v = ld16(a.wmat + ((size_t)row * taps * SCH) * ES + ch * 16);
+        st16(sW + row * wpitch + ch * 16, v);
+    }
+    // origin of the source halo relative to the tile: fwd reads (y - p + r), the data-gradient (y + p - r)
+    const int oy = flip ? a.pad_t - (a.R - 1) : -a.pad_t, ox = flip ? a.pad_l - (a.S - 1) : -a.pad_l;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int b = tile;
+        const int tw = b % tilesW; b /= tilesW;
+        const int th = b % tilesH;
+        const int n = b / tilesH;
+        const int y0 = th * HALO_TH, x0 = tw * HALO_TW;
+        __syncthreads();                                // previous tile's halo reads are done; weights are visible
+        for (int idx = tid; idx < HP * CPV; idx += 512) {
+            int hp = idx / CPV, sub = idx - hp * CPV;
+            int hy = hp / HWd, hx = hp - hy * HWd;
+            int yi = y0 + oy + hy, xi = x0 + ox + hx;
+            bool ok = true;
+            if (a.reflect && !flip) {
+                yi = yi < 0 ? -yi : (yi >= a.H ? 2 * (a.H - 1) - yi : yi);
+                xi = xi < 0 ? -xi : (xi >= a.W ? 2 * (a.W - 1) - xi : xi);
+            } else ok = (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W;
+            u32x4 v = zero16();
+            if (ok) v = ld16(a.src + (((size_t)n * a.H + yi) * a.W + xi) * PXB + sub * 16);
+            st16(sH + hp * PXB + sub * 16, v);
+        }
+        __syncthreads();
+
+        f32x4 acc[4][4];                                // [cout frag][pixel frag]
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < ksteps; ++ks) {
+            int qq = ks * 4 + fq;                        // this lane's 16-byte k-chunk
+            int tap = qq / CPV, sub = qq - tap * CPV;
+            if (tap >= taps) { tap = 0; sub = 0; }       // weights are zero there; keep the halo read in bounds
+            int tr = tap / a.S, ts = tap - tr * a.S;
+            if (flip) { tr = a.R - 1 - tr; ts = a.S - 1 - ts; }
+            u32x4 fw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fw[i] = ld16(sW + (i * 16 + frow) * wpitch + qq * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int y = 2 * wave + (j >> 1), x = (j & 1) * 16 + frow;
+                u32x4 fp = ld16(sH + ((y + tr) * HWd + x + ts) * PXB + sub * 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[i]), __builtin_bit_cast(bf16x8, fp), acc[i][j], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fw[i][e]), __uint_as_float(fp[e]), acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = y0 + 2 * wave + (j >> 1), x = x0 + (j & 1) * 16 + frow;
+            const size_t dpix = ((size_t)n * a.H + y) * a.W + x;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int dc = i * 16 + fq * 4;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[i][j][e] + (a.bias ? a.bias[dc + e] : 0.f), a.act, a.leak);
+                T* o = reinterpret_cast<T*>(a.dst) + dpix * DCH + dc;
+                if constexpr (sizeof(T) == 2) {
+                    bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    *reinterpret_cast<bf16x4*>(o) = pk;
+                } else *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+            }
+        }
+    }
+}
+
+// src_ch / dst_ch: channel counts of the gathered tensor and of the result for the direction in question
+static bool halo_narrow_in_ok(const sgg_conv_desc* d, int src_ch, int dst_ch) {
+    return use_glds() && src_ch == 8 && dst_ch == 64 && d->stride == 1 && d->R <= HALO_MAXR && d->S <= HALO_MAXR &&
+           d->Ho == d->H && d->Wo == d->W && d->H % HALO_TH == 0 && d->W % HALO_TW == 0;
+}
+
+template <typename T>
+static int launch_halo_narrow_in(const sgg_conv_desc* d, const ConvArgs& a, int flip, hipStream_t s) {
+    const int cpv = 8 / (16 / (int)sizeof(T));
+    const int ksteps = (d->R * d->S * cpv + 3) / 4;
+    size_t lds = (size_t)64 * (((ksteps * 4) | 1) * 16) + (size_t)(HALO_TH + d->R - 1) * (HALO_TW + d->S - 1) * 8 * sizeof(T);
+    auto kern = conv_halo_narrow_in_kernel<T>;
+    static bool attr_done = false;
+    if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    int ntiles = d->N * (d->H / HALO_TH) * (d->W / HALO_TW);
+    int blocks = ntiles < 512 ? ntiles : 512;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, s, a, ntiles, flip);
+    return sgg_check_launch();
+}
+
 // Side tensor for the REFLECT data-gradient: for every border pixel (the pixels MirrorPadGrad adds mirrored terms
 // to) and every tap, the gather row the GEMM needs = sum of dy over all preimages of the pixel's padded position.
 // fold[b][tap][k], b enumerating border pixels per image: the 2p border ROW bands first (all columns), then the
@@ -1650,6 +1777,8 @@ int sgg_conv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w, const f
                    void* ws, size_t ws_bytes, void* stream) {
     if (!desc_ok(d) || !x || !w || !y) return SGG_EINVAL;
     ConvArgs a = make_args(d, x, w, bias, y, act, leak);
+    if (halo_narrow_in_ok(d, d->C, d->K))               // narrow input (stem): halo + whole weight matrix resident in LDS
+        return d->dtype == SGG_BF16 ? launch_halo_narrow_in<bf16>(d, a, 0, (hipStream_t)stream) : launch_halo_narrow_in<float>(d, a, 0, (hipStream_t)stream);
     if (use_glds() && halo_fwd_ok(d))                   // narrow output at full resolution: input halo resident in LDS
         return d->dtype == SGG_BF16 ? launch_halo_fwd<bf16>(d, a, (hipStream_t)stream) : launch_halo_fwd<float>(d, a, (hipStream_t)stream);
     return d->dtype == SGG_BF16 ? run_gemm<bf16, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream)
@@ -1671,6 +1800,12 @@ int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w, c
     if (!desc_ok(d) || !dy || !w || !dx) return SGG_EINVAL;
     ConvArgs a = make_args(d, dy, w, nullptr, dx, SGG_ACT_NONE, 0.f);
     a.addend = (const char*)addend;
+    if (!addend && halo_narrow_in_ok(d, d->K, d->C)) {  // data-gradient of a narrow-OUTPUT conv (the head): dy has 8 channels
+        int rc0 = d->dtype == SGG_BF16 ? launch_halo_narrow_in<bf16>(d, a, 1, (hipStream_t)stream) : launch_halo_narrow_in<float>(d, a, 1, (hipStream_t)stream);
+        if (rc0 || !a.reflect) return rc0;
+        // REFLECT: add the mirrored (MirrorPadGrad) terms of the border pixels with the small register-path launch
+        return d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_BORDER>(a, (hipStream_t)stream) : launch_gemm<float, MODE_BORDER>(a, (hipStream_t)stream);
+    }
     const size_t fb = fold_bytes(d);
     if (fb) {
         // v2: pre-fold the gather rows of the border pixels, then ONE GEMM launch reads them like any other source

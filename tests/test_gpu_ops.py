@@ -64,6 +64,9 @@ CONV_CASES = [
     ("h31_like", 3, 2, "VALID", 512, 512, 9, 11),
     ("head_halo_7x7", 7, 1, "REFLECT-3", 64, 3, 32, 64),
     ("head_halo_3x3_same", 3, 1, "SAME", 128, 10, 16, 32),
+    ("stem_halo_7x7", 7, 1, "REFLECT-3", 3, 64, 32, 64),
+    ("stem_halo_3x3_same", 3, 1, "SAME", 8, 64, 16, 32),
+    ("head_dgrad_halo_same", 5, 1, "SAME", 64, 8, 16, 64),
 ]
 
 

@@ -34,7 +34,8 @@ struct ConvArgs {
     const char* fold;    // REFLECT DGRAD (v2): pre-folded gather rows of the border pixels [pixel][tap][K], else nullptr
     float* partial;      // split-K (v2): f32 slabs [ksplit][pdst][DC]
     int ksplit;          // 1 = no split
-    int ablate;          // timing experiments only (SGG_ABLATE): 1 skips the in-loop DMA, 2 skips the LDS reads + MFMAs
+    int ablate;          // timing experiments only (SGG_ABLATE): 1 no in-loop DMA, 2 no LDS reads/MFMAs, 3 = 1 + no barrier,
+                         // 5 prologue + epilogue only, 6 prologue only (results in DESIGN.md section 7)
     size_t pdst;         // destination pixels (slab stride)
     int N, H, W, C, K, R, S, stride, pad_t, pad_l, Ho, Wo, reflect;
     int act;
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
     const int ktot = (nr * ns * cpv + CPR - 1) / CPR;
     const int kper = (ktot + a.ksplit - 1) / a.ksplit;
     const int kt0 = (int)blockIdx.y * kper;
-    const int ktiles = max(0, min(ktot, kt0 + kper) - kt0);
+    const int ktiles = a.ablate >= 5 ? 0 : max(0, min(ktot, kt0 + kper) - kt0);   // ablate 5/6: no main loop
     int t_cc, t_ri, t_si;
     { int q0 = lcc + kt0 * CPR; int ti = q0 / cpv; t_cc = q0 - ti * cpv; t_ri = ns ? ti / ns : nr; t_si = ns ? ti - t_ri * ns : 0; }
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
     for (int kt = 0; kt < ktiles; ++kt) {
         const int cur = kt % NS;
         const bool refill = kt + NS - 1 < ktiles;
-        if (refill && a.ablate != 1) stage_tile((kt + NS - 1) % NS);
+        if (refill && (a.ablate == 0 || a.ablate == 2)) stage_tile((kt + NS - 1) % NS);
         const char* bP = smem + cur * STAGE + (wm * WM + frow) * BKB;
         const char* bQ = smem + cur * STAGE + BM * BKB + (wn * WN + frow) * BKB;
         if (a.ablate != 2) {
@@ -588,11 +589,12 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
         }
         wait_tiles(refill);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (a.ablate < 3) __builtin_amdgcn_s_barrier();
     }
 
     // bias of this lane's 4 output channels per channel tile, fetched once (a per-store load would put a full
     // L2 round trip in front of every one of the NI*MI stores)
+    if (a.ablate == 6) return;
     float bv[NI][4];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
         int m = m0 + wm * WM + j * 16 + frow;
         if (m >= M) continue;
         size_t dpix;
-        if (MODE == MODE_FWD) dpix = (size_t)m;
+        if (MODE == MODE_FWD || st == 1) dpix = (size_t)m;       // stride 1: destination pixel index == GEMM row
         else {
             int n, h, w;
             decode(m, n, h, w);

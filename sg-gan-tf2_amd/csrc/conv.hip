@@ -1399,7 +1399,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_glds_kernel(WgradArgs a) {
                     bf16x8 fa = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
                     for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[i][j], 0, 0, 0);
                 }
             }
         } else {
@@ -1419,7 +1419,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_glds_kernel(WgradArgs a) {
                     float fa = *reinterpret_cast<const float*>(bX + row * PITCH + (((col >> 2) ^ key) << 4) + (col & 3) * 4);
 #pragma unroll
                     for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j], fa, acc[i][j], 0, 0, 0);
                 }
             }
         }
@@ -1427,19 +1427,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_glds_kernel(WgradArgs a) {
         __syncthreads();
     }
 
+    // The dy fragment is the MFMA A operand, so D[row = cout][col = (tap,c)]: lane (g,u) owns couts 4g..4g+3 of row u ->
+    // one 16-byte store per fragment into the [row][cout] slab (4x fewer store instructions than the transposed layout)
     float* slab = a.ws + (size_t)split * Mrows * a.K;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i) {
+        const int mr = m0 + wm * 128 + i * 16 + u;
+        if (mr >= Mrows) continue;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            int k = n0 + wn * 64 + j * 16 + u;
-            if (k >= a.K) continue;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int mr = m0 + wm * 128 + i * 16 + g * 4 + e;
-                if (mr < Mrows) slab[(size_t)mr * a.K + k] = acc[i][j][e];
-            }
+            const int k = n0 + wn * 64 + j * 16 + g * 4;
+            if (k < a.K) *reinterpret_cast<f32x4*>(slab + (size_t)mr * a.K + k) = acc[i][j];
         }
+    }
 }
 
 // dw[tap][c<Cr][k<Kr] (+)= sum_split ws[split][tap*C + c][k]   (fixed summation tree -> deterministic)

@@ -642,6 +642,231 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// 3x3 stride-1 "same" convolution with the INPUT HALO RESIDENT IN LDS (the 18 residual-block convs of the
+// generator, module.py:210-216, are this shape at C = K = 256).
+//
+// conv_gemm_glds_kernel re-fetches a pixel tile once per tap (9x) from L2; at 256x256 tiles that kernel is bound by
+// the L2->LDS stream (DMA-only 62 us vs 49 us of MFMA).  Here a block owns 2 output rows x 128
+// columns; per 64-channel chunk the 4 x 130 input pixels it needs sit in LDS once (REFLECT / zero padding resolved
+// in the DMA's per-lane source address) and the 9 taps read shifted rows of that image, so the pixel operand costs
+// 68 KB instead of 288 KB per chunk and only the weight tiles stream per tap (-38 % L2->LDS bytes overall).
+// The halo is single-buffered and refilled row by row while other rows are in use: kernel row r touches halo rows
+// r and r+1 only, so row 0 of the next chunk is loaded during r=1, row 1 during r=2, rows 2/3 during r=0/1 of the
+// next chunk.  K order: chunk-major, tap-minor.  Weight tiles: the same 2-stage DMA ring as above.
+// -------------------------------------------------------------------------------------------------
+#define H3_TW 128
+#define H3_PITCH 136                                   // halo row pitch in pixels (130 used; multiple of 8 = one DMA)
+#define H3_HALO_BYTES (4 * H3_PITCH * 128)
+#define H3_LDS (H3_HALO_BYTES + 2 * 256 * 128)
+
+template <int MODE>
+__global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
+    constexpr int BN = 256, WGM = 2, WGN = 4, WM = 128, WN = 64, MI = 8, NI = 4, BKB = 128, KK = 2;
+    constexpr int QA = 4;                              // weight rows per thread per tile (8 waves x 8 rows x 4)
+    constexpr int RPP = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sH = smem;                                   // halo [4][H3_PITCH][128 B]
+    char* sB = smem + H3_HALO_BYTES;                   // 2 x [256][128 B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int SC = (MODE == MODE_FWD) ? a.C : a.K;     // source channels (GEMM K per tap)
+    const int DC = (MODE == MODE_FWD) ? a.K : a.C;
+    const int wrow = 9 * SC;
+    const int nchunk = SC >> 6;
+
+    const int tilesN = (DC + BN - 1) / BN;
+    const int tilesW = a.W / H3_TW, tilesH = a.H >> 1;
+    int lid;
+    {
+        const int b = (int)blockIdx.x, nm = (int)gridDim.x;
+        const int q = nm >> 3, rr = nm & 7, xcd = b & 7;
+        lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
+    }
+    const int n0 = (lid % tilesN) * BN;
+    int mt = lid / tilesN;
+    const int tw = mt % tilesW; mt /= tilesW;
+    const int th = mt % tilesH;
+    const int img = mt / tilesH;
+    const int h0 = th * 2, w0 = tw * H3_TW;
+
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+    // ---- halo DMA: one wave-instruction = 8 halo pixels x 128 B; a halo row is 17 of them (wave, wave+8, wave+16)
+    const int hpos = lane & 7, hsub = lane >> 3;
+    auto load_halo_row = [&](int k, int chunk) {
+        int hi = h0 - 1 + k;
+        bool rowok = true;
+        if (a.reflect) hi = hi < 0 ? -hi : (hi >= a.H ? 2 * (a.H - 1) - hi : hi);
+        else rowok = (unsigned)hi < (unsigned)a.H;
+        const char* rowp = a.src + ((size_t)img * a.H + (rowok ? hi : 0)) * a.W * SC * 2 + chunk * 128;
+#pragma unroll
+        for (int qi = 0; qi < 3; ++qi) {
+            const int q = wave + 8 * qi;
+            if (q >= 17) break;
+            const int hp = q * 8 + hsub;                                   // halo column 0..135
+            int wi = w0 - 1 + hp;
+            bool ok = rowok && hp < H3_TW + 2;
+            if (a.reflect) wi = wi < 0 ? -wi : (wi >= a.W ? 2 * (a.W - 1) - wi : wi);
+            else ok = ok && (unsigned)wi < (unsigned)a.W;
+            const int key = (((k * H3_PITCH + hp) >> 1) & 7);
+            const char* src = ok ? rowp + (size_t)wi * SC * 2 + ((hpos ^ key) << 4) : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sH + (k * H3_PITCH + q * 8) * 128), 16, 0, 0);
+        }
+    };
+
+    // ---- weight-tile DMA (as in conv_gemm_glds_kernel): row = tid/8 + 64*i at position tid%8
+    const int srow0 = tid >> 3;
+    const int lcc = (tid & 7) ^ ((srow0 >> 1) & 7);
+    const char* qrow[QA];
+    unsigned qok = 0;
+#pragma unroll
+    for (int i = 0; i < QA; ++i) {
+        const int dc = n0 + srow0 + RPP * i;
+        qrow[i] = zero;
+        if (dc < DC) { qrow[i] = a.wmat + (size_t)dc * wrow * 2 + lcc * 16; qok |= 1u << i; }
+    }
+    auto load_w = [&](int stg, int chunk, int tap) {
+        const int off = (tap * SC + chunk * 64) * 2;
+        char* sQ = sB + stg * (256 * 128);
+#pragma unroll
+        for (int i = 0; i < QA; ++i) {
+            const char* src = qrow[i] + (((qok >> i) & 1u) ? off : 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sQ + (wave * 8 + RPP * i) * 128), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fswQ = ((wn * WN + frow) >> 1) & 7;
+
+    // prologue: whole halo of chunk 0 + weight tile 0
+#pragma unroll
+    for (int k = 0; k < 4; ++k) load_halo_row(k, 0);
+    load_w(0, 0, MODE == MODE_FWD ? 0 : 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const int ntiles = a.ablate >= 5 ? 0 : nchunk * 9;
+    int chunk = 0, tap = 0;                           // of the tile being multiplied
+    for (int t = 0; t < ntiles; ++t) {
+        // refill: next weight tile, and the halo rows whose slots are free (see header)
+        if (a.ablate == 0 || a.ablate == 2) {
+            int ntap = tap + 1, nchk = chunk;
+            if (ntap == 9) { ntap = 0; ++nchk; }
+            if (t + 1 < ntiles) load_w((t + 1) & 1, nchk, MODE == MODE_FWD ? ntap : 8 - ntap);
+            if (tap == 0 && chunk > 0) load_halo_row(2, chunk);
+            if (tap == 3) {
+                if (chunk > 0) load_halo_row(3, chunk);
+                if (chunk + 1 < nchunk) load_halo_row(0, chunk + 1);
+            }
+            if (tap == 6 && chunk + 1 < nchunk) load_halo_row(1, chunk + 1);
+        }
+        const int r = tap / 3, sx = tap - 3 * r;
+        // halo offset (r, sx) pairs with weight tap (r, sx) forward and with the flipped tap (2-r, 2-sx) = 8 - tap in
+        // the data gradient, so both modes walk the halo rows in the same order (the refill schedule relies on it)
+        const int hr = wm + r;                                             // halo row of this wave's output row
+        const int hc = frow + sx;                                          // halo column of fragment 0
+        const int fswP = (((hr * H3_PITCH + hc) >> 1) & 7);                // same for every fragment (16 | fragment step)
+        const char* bP = sH + (hr * H3_PITCH + hc) * 128;
+        const char* bQ = sB + (t & 1) * (256 * 128) + (wn * WN + frow) * 128;
+        if (a.ablate != 2) {
+            constexpr int GJ = 4, GPK = MI / GJ, NG = KK * GPK;
+            u32x4 fw[KK][NI];
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) fw[kk][i] = ld16(bQ + i * 16 * BKB + (((fq + 4 * kk) ^ fswQ) << 4));
+            u32x4 fp[2][GJ];
+#pragma unroll
+            for (int jj = 0; jj < GJ; ++jj) fp[0][jj] = ld16(bP + jj * 16 * BKB + ((fq ^ fswP) << 4));
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int kk = g / GPK, jb = (g % GPK) * GJ;
+                if (g + 1 < NG) {
+                    const int kn = (g + 1) / GPK, jn = ((g + 1) % GPK) * GJ;
+#pragma unroll
+                    for (int jj = 0; jj < GJ; ++jj)
+                        fp[(g + 1) & 1][jj] = ld16(bP + (jn + jj) * 16 * BKB + (((fq + 4 * kn) ^ fswP) << 4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int jj = 0; jj < GJ; ++jj)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+                        acc[i][jb + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fw[kk][i]), __builtin_bit_cast(bf16x8, fp[g & 1][jj]), acc[i][jb + jj], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (a.ablate < 3) __builtin_amdgcn_s_barrier();
+        if (++tap == 9) { tap = 0; ++chunk; }
+    }
+
+    if (a.ablate == 6) return;
+    float bv[NI][4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int dc = n0 + wn * WN + i * 16 + fq * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[i][e] = (a.bias && dc < DC) ? a.bias[dc + e] : 0.f;
+    }
+    const size_t prow = ((size_t)img * a.H + h0 + wm) * a.W + w0;
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+        const size_t dpix = prow + j * 16 + frow;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int dc = n0 + wn * WN + i * 16 + fq * 4;
+            if (dc >= DC) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[i][j][e] + bv[i][e], a.act, a.leak);
+            if (a.addend) {
+                const bf16* ad = reinterpret_cast<const bf16*>(a.addend) + dpix * DC + dc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)ad[e];
+            }
+            bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.dst) + dpix * DC + dc) = pk;
+        }
+    }
+}
+
+// shapes the halo-resident kernel takes: 3x3, stride 1, pad 1 on a same-size output, bf16, 64 | source channels,
+// 128 | W, even H; REFLECT only forward (the REFLECT data gradient needs the mirrored border terms)
+static bool halo3_ok(const ConvArgs& a, int mode, bool is_bf16) {
+    static int en = -1;
+    if (en < 0) { const char* e = getenv("SGG_HALO3"); en = e ? atoi(e) : 1; }
+    if (!en || !is_bf16 || !use_glds() || a.ksplit > 1) return false;
+    if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad_t != 1 || a.pad_l != 1 || a.Ho != a.H || a.Wo != a.W) return false;
+    if (a.W % H3_TW || (a.H & 1)) return false;
+    const int SC = mode == MODE_FWD ? a.C : a.K;
+    if (SC % 64) return false;
+    if (mode == MODE_DGRAD && a.reflect) return false;
+    return mode == MODE_FWD || mode == MODE_DGRAD;
+}
+
+template <int MODE>
+static int launch_halo3(const ConvArgs& a, hipStream_t s) {
+    auto kern = conv3x3_halo_gemm_kernel<MODE>;
+    static bool attr_done = false;
+    if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H3_LDS); attr_done = true; }
+    const int DC = MODE == MODE_FWD ? a.K : a.C;
+    const int64_t blocks = (int64_t)a.N * (a.H / 2) * (a.W / H3_TW) * ((DC + 255) / 256);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), H3_LDS, s, a);
+    return sgg_check_launch();
+}
+
+// -------------------------------------------------------------------------------------------------
 // Narrow-output convolution (Cout <= 16, stride 1, same-size output): the generator head, 7x7 64->3 at full
 // resolution (module.py:262-264).  As an implicit GEMM it would re-read every input pixel once per tap (49x) from
 // L2 for a 16-wide output tile; here the block keeps the input HALO of its 16x32-pixel output tile in LDS (one
@@ -1593,6 +1818,9 @@ static int launch_gemm(const ConvArgs& a, hipStream_t s) {
     } else {
         DC = a.C; classes = a.stride * a.stride;
         Mmax = (int64_t)a.N * ((a.H + a.stride - 1) / a.stride) * ((a.W + a.stride - 1) / a.stride);
+    }
+    if constexpr (MODE != MODE_BORDER && sizeof(T) == 2) {
+        if (halo3_ok(a, MODE, true)) return launch_halo3<MODE>(a, s);
     }
     if constexpr (MODE != MODE_BORDER) {
         if (use_glds()) {

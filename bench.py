@@ -303,7 +303,7 @@ def main():
                 kt[tag[0]] = {"avg_ms": ms, "launches": n, "gbs": by / (ms * 1e-3) / 1e9, "mbytes_per_launch": by / 1e6}
         if "res_conv_fwd" in kt:
             k = kt["res_conv_fwd"]
-            line["roofline"] = {"bound": "mfma", "kernel": "conv_gemm_glds_kernel<bf16,FWD,256,256,8 waves> (3x3 C=256 residual-block conv)",
+            line["roofline"] = {"bound": "mfma", "kernel": "conv3x3_halo_gemm_kernel<FWD> (bf16, 256x256 tile, 8 waves, input halo resident in LDS; 3x3 C=256 residual-block conv)",
                                 "achieved": k["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                 "frac": k["tflops"] / PEAK_BF16_TFLOPS, "traffic": measured_traffic("res_conv_fwd"),
                                 "avg_launch_ms": k["avg_ms"], "launches_timed": k["launches"], "gflop_per_launch": k["gflop_per_launch"]}

@@ -657,9 +657,19 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
 #define H3_TW 128
 #define H3_PITCH 136                                   // halo row pitch in pixels (130 used; multiple of 8 = one DMA)
 #define H3_HALO_BYTES (4 * H3_PITCH * 128)
+#define H3_PATCH_ROWS 40                               // 2 tile rows x 2 sides x 9 taps = 36, rounded to whole DMAs
 #define H3_LDS (H3_HALO_BYTES + 2 * 256 * 128)
+#define H3_LDS_FOLD (H3_LDS + 2 * H3_PATCH_ROWS * 128)
 
-template <int MODE>
+// FOLD = data gradient of a REFLECT-padded conv (MirrorPadGrad folded into the gather, module.py:209-216 backward).
+// With pad 1 the mirrored terms reach image rows 1 and H-2 and columns 1 and W-2 only:
+//   rows   : output row 1 needs (dy[2] + dy[0]) where it would read dy[2], and only that row of the top tile reads
+//            that halo slot (same for dy[H-3] + dy[H-1] in the bottom tile), so the slot is filled from a
+//            pre-summed "virtual row" (a.fold, second part) -- no change to the fragment reads;
+//   columns: the two pixels per tile row in columns 1 / W-2 read their gather row per tap from a small LDS patch
+//            (2 x 2 x 9 rows per chunk, from a.fold's first part, which holds the complete mirrored sums for those
+//            pixels) through a per-lane address select in the first / last pixel fragment.
+template <int MODE, bool FOLD>
 __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     constexpr int BN = 256, WGM = 2, WGN = 4, WM = 128, WN = 64, MI = 8, NI = 4, BKB = 128, KK = 2;
     constexpr int QA = 4;                              // weight rows per thread per tile (8 waves x 8 rows x 4)
@@ -667,6 +677,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sH = smem;                                   // halo [4][H3_PITCH][128 B]
     char* sB = smem + H3_HALO_BYTES;                   // 2 x [256][128 B]
+    char* sPatch = smem + H3_LDS;                      // FOLD: 2 x [H3_PATCH_ROWS][128 B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -694,12 +705,18 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
 
     // ---- halo DMA: one wave-instruction = 8 halo pixels x 128 B; a halo row is 17 of them (wave, wave+8, wave+16)
     const int hpos = lane & 7, hsub = lane >> 3;
+    const bool mirror = MODE == MODE_FWD && a.reflect;                     // the data gradient always zero-pads dy
+    const char* vrows = FOLD ? a.fold + (size_t)a.N * a.H * 18 * SC * 2 : nullptr;   // [N][2][W][SC] after the patches
     auto load_halo_row = [&](int k, int chunk) {
         int hi = h0 - 1 + k;
         bool rowok = true;
-        if (a.reflect) hi = hi < 0 ? -hi : (hi >= a.H ? 2 * (a.H - 1) - hi : hi);
+        if (mirror) hi = hi < 0 ? -hi : (hi >= a.H ? 2 * (a.H - 1) - hi : hi);
         else rowok = (unsigned)hi < (unsigned)a.H;
         const char* rowp = a.src + ((size_t)img * a.H + (rowok ? hi : 0)) * a.W * SC * 2 + chunk * 128;
+        if (FOLD) {
+            if (h0 == 0 && k == 3) rowp = vrows + ((size_t)img * 2 + 0) * a.W * SC * 2 + chunk * 128;
+            if (h0 == a.H - 2 && k == 0) rowp = vrows + ((size_t)img * 2 + 1) * a.W * SC * 2 + chunk * 128;
+        }
 #pragma unroll
         for (int qi = 0; qi < 3; ++qi) {
             const int q = wave + 8 * qi;
@@ -707,13 +724,28 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             const int hp = q * 8 + hsub;                                   // halo column 0..135
             int wi = w0 - 1 + hp;
             bool ok = rowok && hp < H3_TW + 2;
-            if (a.reflect) wi = wi < 0 ? -wi : (wi >= a.W ? 2 * (a.W - 1) - wi : wi);
+            if (mirror) wi = wi < 0 ? -wi : (wi >= a.W ? 2 * (a.W - 1) - wi : wi);
             else ok = ok && (unsigned)wi < (unsigned)a.W;
             const int key = (((k * H3_PITCH + hp) >> 1) & 7);
             const char* src = ok ? rowp + (size_t)wi * SC * 2 + ((hpos ^ key) << 4) : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(sH + (k * H3_PITCH + q * 8) * 128), 16, 0, 0);
         }
+    };
+
+    // ---- FOLD: column patch, row pe = (tile row * 2 + side) * 9 + tap (halo tap order), 5 DMAs by waves 0..4
+    const bool hasL = FOLD && tw == 0, hasR = FOLD && tw == tilesW - 1;
+    auto load_patch = [&](int chunk) {
+        if (!FOLD || wave >= H3_PATCH_ROWS / 8) return;
+        const int pe = wave * 8 + hsub;
+        const int tap_h = pe % 9, side = (pe / 9) & 1, tr = pe / 18;
+        const bool ok = pe < 36 && (side ? hasR : hasL);
+        const int key = (pe >> 1) & 7;
+        // a.fold first part: [N][H][2 sides][9 weight taps][SC]; halo tap t pairs with weight tap 8 - t
+        const char* src = ok ? a.fold + (((((size_t)img * a.H + h0 + tr) * 2 + side) * 9 + (8 - tap_h)) * SC + chunk * 64) * 2 + ((hpos ^ key) << 4)
+                             : zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sPatch + ((chunk & 1) * H3_PATCH_ROWS + wave * 8) * 128), 16, 0, 0);
     };
 
     // ---- weight-tile DMA (as in conv_gemm_glds_kernel): row = tid/8 + 64*i at position tid%8
@@ -750,6 +782,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     // prologue: whole halo of chunk 0 + weight tile 0
 #pragma unroll
     for (int k = 0; k < 4; ++k) load_halo_row(k, 0);
+    load_patch(0);
     load_w(0, 0, MODE == MODE_FWD ? 0 : 8);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -765,7 +798,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             if (tap == 0 && chunk > 0) load_halo_row(2, chunk);
             if (tap == 3) {
                 if (chunk > 0) load_halo_row(3, chunk);
-                if (chunk + 1 < nchunk) load_halo_row(0, chunk + 1);
+                if (chunk + 1 < nchunk) { load_halo_row(0, chunk + 1); load_patch(chunk + 1); }
             }
             if (tap == 6 && chunk + 1 < nchunk) load_halo_row(1, chunk + 1);
         }
@@ -777,6 +810,20 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         const int fswP = (((hr * H3_PITCH + hc) >> 1) & 7);                // same for every fragment (16 | fragment step)
         const char* bP = sH + (hr * H3_PITCH + hc) * 128;
         const char* bQ = sB + (t & 1) * (256 * 128) + (wn * WN + frow) * 128;
+        // FOLD: the lanes holding pixel column 1 (fragment 0) / W-2 (fragment MI-1) read their patch row instead
+        const int peL = (wm * 2 + 0) * 9 + tap, peR = (wm * 2 + 1) * 9 + tap;
+        const char* pL = sPatch + ((chunk & 1) * H3_PATCH_ROWS + peL) * 128;
+        const char* pR = sPatch + ((chunk & 1) * H3_PATCH_ROWS + peR) * 128;
+        const int keyL = (peL >> 1) & 7, keyR = (peR >> 1) & 7;
+        const bool isL = hasL && frow == 1, isR = hasR && frow == 14;
+        auto ldP = [&](int j, int kk) -> u32x4 {
+            const char* p = bP + j * 16 * BKB + (((fq + 4 * kk) ^ fswP) << 4);
+            if (FOLD) {
+                if (j == 0 && isL) p = pL + (((fq + 4 * kk) ^ keyL) << 4);
+                if (j == MI - 1 && isR) p = pR + (((fq + 4 * kk) ^ keyR) << 4);
+            }
+            return ld16(p);
+        };
         if (a.ablate != 2) {
             constexpr int GJ = 4, GPK = MI / GJ, NG = KK * GPK;
             u32x4 fw[KK][NI];
@@ -786,15 +833,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
                 for (int i = 0; i < NI; ++i) fw[kk][i] = ld16(bQ + i * 16 * BKB + (((fq + 4 * kk) ^ fswQ) << 4));
             u32x4 fp[2][GJ];
 #pragma unroll
-            for (int jj = 0; jj < GJ; ++jj) fp[0][jj] = ld16(bP + jj * 16 * BKB + ((fq ^ fswP) << 4));
+            for (int jj = 0; jj < GJ; ++jj) fp[0][jj] = ldP(jj, 0);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int kk = g / GPK, jb = (g % GPK) * GJ;
                 if (g + 1 < NG) {
                     const int kn = (g + 1) / GPK, jn = ((g + 1) % GPK) * GJ;
 #pragma unroll
-                    for (int jj = 0; jj < GJ; ++jj)
-                        fp[(g + 1) & 1][jj] = ld16(bP + (jn + jj) * 16 * BKB + (((fq + 4 * kn) ^ fswP) << 4));
+                    for (int jj = 0; jj < GJ; ++jj) fp[(g + 1) & 1][jj] = ldP(jn + jj, kn);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -848,22 +894,68 @@ static bool halo3_ok(const ConvArgs& a, int mode, bool is_bf16) {
     if (en < 0) { const char* e = getenv("SGG_HALO3"); en = e ? atoi(e) : 1; }
     if (!en || !is_bf16 || !use_glds() || a.ksplit > 1) return false;
     if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad_t != 1 || a.pad_l != 1 || a.Ho != a.H || a.Wo != a.W) return false;
-    if (a.W % H3_TW || (a.H & 1)) return false;
+    if (a.W % H3_TW || (a.H & 1) || a.H < 4) return false;
     const int SC = mode == MODE_FWD ? a.C : a.K;
     if (SC % 64) return false;
-    if (mode == MODE_DGRAD && a.reflect) return false;
     return mode == MODE_FWD || mode == MODE_DGRAD;
 }
 
-template <int MODE>
+template <int MODE, bool FOLD>
 static int launch_halo3(const ConvArgs& a, hipStream_t s) {
-    auto kern = conv3x3_halo_gemm_kernel<MODE>;
+    auto kern = conv3x3_halo_gemm_kernel<MODE, FOLD>;
+    constexpr int lds = FOLD ? H3_LDS_FOLD : H3_LDS;
     static bool attr_done = false;
-    if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H3_LDS); attr_done = true; }
+    if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
     const int DC = MODE == MODE_FWD ? a.K : a.C;
     const int64_t blocks = (int64_t)a.N * (a.H / 2) * (a.W / H3_TW) * ((DC + 255) / 256);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), H3_LDS, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, a);
     return sgg_check_launch();
+}
+
+// Side tensor of the FOLD variant: [N][H][2 sides][9 taps][K] complete mirrored gather rows of the pixels in columns
+// 1 and W-2, then [N][2][W][K] virtual rows dy[2]+dy[0] and dy[H-3]+dy[H-1]   (pad 1)
+template <typename T>
+__global__ __launch_bounds__(256) void fold_halo_gather_kernel(const char* dy, char* fold, int N, int H, int W, int K) {
+    constexpr int VEC = ET<T>::VEC;
+    const int cpv = K / VEC;
+    const int64_t npatch = (int64_t)N * H * 18 * cpv, total = npatch + (int64_t)N * 2 * W * cpv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+        if (i < npatch) {
+            int ch = (int)(i % cpv);
+            int64_t t = i / cpv;
+            int tap = (int)(t % 9); t /= 9;
+            int side = (int)(t & 1); t >>= 1;
+            int h = (int)(t % H), n = (int)(t / H);
+            int w = side ? W - 2 : 1, r = tap / 3, s = tap - 3 * r;
+            int jh[3], jw[3];
+            int nh = reflect_preimages(h, H, 1, jh), nw = reflect_preimages(w, W, 1, jw);
+            for (int ia = 0; ia < nh; ++ia)
+                for (int ib = 0; ib < nw; ++ib) {
+                    int ho = jh[ia] - r, wo = jw[ib] - s;
+                    if ((unsigned)ho < (unsigned)H && (unsigned)wo < (unsigned)W) {
+                        float v[VEC];
+                        ET<T>::unpack(ld16(dy + ((((size_t)n * H + ho) * W + wo) * K + (size_t)ch * VEC) * sizeof(T)), v);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc[e] += v[e];
+                    }
+                }
+        } else {
+            int64_t t = i - npatch;
+            int ch = (int)(t % cpv); t /= cpv;
+            int w = (int)(t % W); t /= W;
+            int which = (int)(t & 1), n = (int)(t >> 1);
+            int ha = which ? H - 3 : 2, hb = which ? H - 1 : 0;
+            float va[VEC], vb[VEC];
+            ET<T>::unpack(ld16(dy + ((((size_t)n * H + ha) * W + w) * K + (size_t)ch * VEC) * sizeof(T)), va);
+            ET<T>::unpack(ld16(dy + ((((size_t)n * H + hb) * W + w) * K + (size_t)ch * VEC) * sizeof(T)), vb);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = va[e] + vb[e];
+        }
+        st16(fold + (size_t)i * 16, ET<T>::pack(acc));
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1820,7 +1912,10 @@ static int launch_gemm(const ConvArgs& a, hipStream_t s) {
         Mmax = (int64_t)a.N * ((a.H + a.stride - 1) / a.stride) * ((a.W + a.stride - 1) / a.stride);
     }
     if constexpr (MODE != MODE_BORDER && sizeof(T) == 2) {
-        if (halo3_ok(a, MODE, true)) return launch_halo3<MODE>(a, s);
+        if (halo3_ok(a, MODE, true)) {
+            if constexpr (MODE == MODE_DGRAD) { if (a.reflect) return launch_halo3<MODE_DGRAD, true>(a, s); }
+            return launch_halo3<MODE, false>(a, s);
+        }
     }
     if constexpr (MODE != MODE_BORDER) {
         if (use_glds()) {
@@ -2042,8 +2137,13 @@ int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w, c
         if (!ws || ws_bytes < fb) return SGG_EWORKSPACE;
         size_t es = d->dtype == SGG_BF16 ? 2 : 4;
         int64_t total = (int64_t)d->N * fold_border_per_image(d->H, d->W, d->pad_t) * d->R * d->S * d->K * es / 16;
+        GemmPlan gp = plan_gemm(d, MODE_DGRAD);
+        ConvArgs probe = a; probe.ksplit = gp.ksplit;
+        const bool halo3 = halo3_ok(probe, MODE_DGRAD, d->dtype == SGG_BF16);
+        if (halo3) total = ((int64_t)d->N * d->H * 18 + (int64_t)d->N * 2 * d->W) * d->K * es / 16;   // smaller side tensor
         int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
-        if (d->dtype == SGG_BF16) hipLaunchKernelGGL(fold_gather_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char*)dy, (char*)ws, d->N, d->H, d->W, d->K, d->R, d->S, d->pad_t, d->Ho, d->Wo);
+        if (halo3) hipLaunchKernelGGL(fold_halo_gather_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char*)dy, (char*)ws, d->N, d->H, d->W, d->K);
+        else if (d->dtype == SGG_BF16) hipLaunchKernelGGL(fold_gather_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char*)dy, (char*)ws, d->N, d->H, d->W, d->K, d->R, d->S, d->pad_t, d->Ho, d->Wo);
         else hipLaunchKernelGGL(fold_gather_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char*)dy, (char*)ws, d->N, d->H, d->W, d->K, d->R, d->S, d->pad_t, d->Ho, d->Wo);
         a.fold = (const char*)ws;
     }

@@ -68,7 +68,8 @@ CONV_CASES = [
     ("stem_halo_3x3_same", 3, 1, "SAME", 8, 64, 16, 32),
     ("head_dgrad_halo_same", 5, 1, "SAME", 64, 8, 16, 64),
     ("halo3_reflect", 3, 1, "REFLECT-1", 64, 256, 4, 128),        # LDS-resident 3x3 halo GEMM (bf16), one chunk
-    ("halo3_reflect_chunks", 3, 1, "REFLECT-1", 192, 320, 2, 128),  # 3 chunks (halo refill schedule), 2 channel tiles
+    ("halo3_reflect_chunks", 3, 1, "REFLECT-1", 192, 320, 4, 128),  # 3 / 5 chunks (halo refill schedule), 2 channel tiles
+    ("halo3_reflect_wide", 3, 1, "REFLECT-1", 64, 64, 6, 256),    # two column tiles: left / right mirror patches apart
     ("halo3_same_tail", 3, 1, "SAME", 128, 192, 6, 256),          # zero padding fwd + dgrad, column tiles, tails
 ]
 

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsggan.so")
+LIB_PATH = os.environ.get("SGG_LIB_PATH") or os.path.join(_HERE, "libsggan.so")   # override: A/B timing of two builds
 
 SGG_F32, SGG_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3

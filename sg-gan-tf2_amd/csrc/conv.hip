@@ -1597,7 +1597,10 @@ template <typename T> __device__ inline int wg2_key(int row) {
     else return (row & 3) << 1;
 }
 
-template <typename T>
+// ROWFAST (Wo % BKP == 0): every K-stage lies inside one output row, so image / row / validity of the gathered x row are
+// block-uniform (scalar) and a lane only resolves its column; the general path divides per lane and per pass, which
+// cost ~20 us of 125 at the residual-block shape (all 8 waves do address arithmetic at the same time, MFMA pipe idle).
+template <typename T, bool ROWFAST>
 __global__ __launch_bounds__(512) void conv_wgrad_glds_kernel(WgradArgs a) {
     constexpr int VEC = ET<T>::VEC;
     constexpr int ES = (int)sizeof(T);
@@ -1644,6 +1647,34 @@ __global__ __launch_bounds__(512) void conv_wgrad_glds_kernel(WgradArgs a) {
     auto stage_tile = [&](int stg, int p0) {
         char* sX = smem + stg * STAGE;
         char* sD = sX + TILE;
+        if constexpr (ROWFAST) {
+            // p0 is uniform and a multiple of BKP; P and the split size are multiples of BKP too: no tail, no row crossing
+            const uint32_t n = fdiv((uint32_t)p0, a.dHW), rem = (uint32_t)p0 - n * a.dHW.d;
+            const uint32_t ho = fdiv(rem, a.dW), wo0 = rem - ho * a.dW.d;
+            int hi = (int)ho * a.stride - a.pad_t + tr;
+            bool rowok = true;
+            if (a.reflect) hi = hi < 0 ? -hi : (hi >= a.H ? 2 * (a.H - 1) - hi : hi);
+            else rowok = (unsigned)hi < (unsigned)a.H;
+            const char* xrow = a.x + ((size_t)n * a.H + (rowok ? hi : 0)) * a.W * a.C * ES + c0 * ES;
+            const char* drow = a.dy + ((size_t)p0 * a.K + n0 + lc * VEC) * ES;
+            const int wbase = (int)wo0 * a.stride - a.pad_l + ts;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int prow = prow0 + RPS * i;
+                int wi = wbase + prow * a.stride;
+                bool ok = rowok && xcol_ok;
+                if (a.reflect) wi = wi < 0 ? -wi : (wi >= a.W ? 2 * (a.W - 1) - wi : wi);
+                else ok = ok && (unsigned)wi < (unsigned)a.W;
+                const char* sx = ok ? xrow + (uint32_t)(wi * a.C * ES) : zero;
+                const char* sd = dcol_ok ? drow + (uint32_t)(prow * a.K * ES) : zero;
+                const int wrow = (wave * 64) / NCH + RPS * i;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx,
+                                                 (__attribute__((address_space(3))) void*)(sX + wrow * PITCH), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sd,
+                                                 (__attribute__((address_space(3))) void*)(sD + wrow * PITCH), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int prow = prow0 + RPS * i, p = p0 + prow;
@@ -1689,35 +1720,43 @@ __global__ __launch_bounds__(512) void conv_wgrad_glds_kernel(WgradArgs a) {
         const char* bX = smem + cur * STAGE;
         const char* bD = bX + TILE;
         if constexpr (sizeof(T) == 2) {
+            // Fragment pipeline as in conv_gemm_glds_kernel: every dy fragment of the stage up front, x fragments in
+            // groups of GJ fetched one group ahead of the MFMAs that consume them (the transposing reads otherwise sit
+            // directly in front of their MFMAs and their latency is exposed whenever the DMA shares the LDS port).
             const int q = u >> 2, pp = u & 3;
-#pragma unroll
-            for (int k32 = 0; k32 < BKP / 32; ++k32) {
-                const int r0 = k32 * 32 + 8 * g + q, r1 = r0 + 4;
+            constexpr int KK = BKP / 32, GJ = 4, GPK = MI / GJ, NG = KK * GPK;
+            auto ldT = [&](const char* base, int kk, int col) -> bf16x8 {
+                const int r0 = kk * 32 + 8 * g + q, r1 = r0 + 4;
                 const int k0 = wg2_key<T>(r0) & (NCH - 1), k1 = wg2_key<T>(r1) & (NCH - 1);
-                bf16x8 fb[NI];
+                const int ch = col >> 3, sub = (col & 7) * 2;
+                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(base + r0 * PITCH + ((ch ^ k0) << 4) + sub));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(base + r1 * PITCH + ((ch ^ k1) << 4) + sub));
+                return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            };
+            bf16x8 fb[KK][NI];
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    int col = wn * 64 + j * 16 + 4 * pp;
-                    int ch = col >> 3, sub = (col & 7) * 2;
-                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4*)(bD + r0 * PITCH + ((ch ^ k0) << 4) + sub));
-                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4*)(bD + r1 * PITCH + ((ch ^ k1) << 4) + sub));
-                    fb[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) fb[kk][j] = ldT(bD, kk, wn * 64 + j * 16 + 4 * pp);
+            bf16x8 fa[2][GJ];
+#pragma unroll
+            for (int ii = 0; ii < GJ; ++ii) fa[0][ii] = ldT(bX, 0, wm * 128 + ii * 16 + 4 * pp);
+#pragma unroll
+            for (int gg = 0; gg < NG; ++gg) {
+                const int kk = gg / GPK, ib = (gg % GPK) * GJ;
+                if (gg + 1 < NG) {
+                    const int kn = (gg + 1) / GPK, in = ((gg + 1) % GPK) * GJ;
+#pragma unroll
+                    for (int ii = 0; ii < GJ; ++ii) fa[(gg + 1) & 1][ii] = ldT(bX, kn, wm * 128 + (in + ii) * 16 + 4 * pp);
                 }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    int col = wm * 128 + i * 16 + 4 * pp;
-                    int ch = col >> 3, sub = (col & 7) * 2;
-                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4*)(bX + r0 * PITCH + ((ch ^ k0) << 4) + sub));
-                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4*)(bX + r1 * PITCH + ((ch ^ k1) << 4) + sub));
-                    bf16x8 fa = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                for (int ii = 0; ii < GJ; ++ii)
 #pragma unroll
                     for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[i][j], 0, 0, 0);
-                }
+                        acc[ib + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[gg & 1][ii], acc[ib + ii][j], 0, 0, 0);
             }
         } else {
 #pragma unroll
@@ -2055,11 +2094,18 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
     int rc;
     if (wgrad_use_v2(d)) {
         constexpr size_t lds = 2 * 2 * (size_t)(sizeof(T) == 2 ? 64 : 32) * 256 * sizeof(T);
-        auto kern = conv_wgrad_glds_kernel<T>;
         static bool attr_done = false;
-        if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+        if (!attr_done) {
+            hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
         dim3 grid((unsigned)(((d->R * d->S * d->C + 255) / 256) * ((d->K + 255) / 256) * splits));
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
+        const int bkp = sizeof(T) == 2 ? 64 : 32;                      // pixels per stage (BKP in the kernel)
+        static int rf = -1;
+        if (rf < 0) { const char* e = getenv("SGG_WGRAD_ROWFAST"); rf = e ? atoi(e) : 1; }
+        if (rf && d->Wo % bkp == 0) hipLaunchKernelGGL((conv_wgrad_glds_kernel<T, true>), grid, dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((conv_wgrad_glds_kernel<T, false>), grid, dim3(512), lds, s, a);
         rc = sgg_check_launch();
     } else if (d->K >= 128) rc = launch_wgrad_cfg<T, 128, 128, 2>(a, splits, s);
     else if (d->K > 16) rc = launch_wgrad_cfg<T, 128, 64, 4>(a, splits, s);

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     char* sP = smem;                    // [2][BM][128]
     char* sQ = smem + 2 * BM * 128;     // [2][BN][128]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar
     const int wm = wave / WGN, wn = wave % WGN;
     const int st = (MODE == MODE_DGRAD) ? a.stride : 1;      // tap-enumeration step
     const int ph = (MODE == MODE_DGRAD) ? (int)blockIdx.z / a.stride : 0;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];   // NS stages of { P [BM][BKB], Q [BNR][BKB] }
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar
     const int wm = wave / WGN, wn = wave % WGN;
     const int st = (MODE == MODE_DGRAD) ? a.stride : 1;
     const int ph = (MODE == MODE_DGRAD) ? (int)blockIdx.z / a.stride : 0;
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     char* sB = smem + H3_HALO_BYTES;                   // 2 x [256][128 B]
     char* sPatch = smem + H3_LDS;                      // FOLD: 2 x [H3_PATCH_ROWS][128 B]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar
     const int wm = wave / WGN, wn = wave % WGN;
     const int SC = (MODE == MODE_FWD) ? a.C : a.K;     // source channels (GEMM K per tap)
     const int DC = (MODE == MODE_FWD) ? a.K : a.C;
@@ -979,7 +979,7 @@ __global__ __launch_bounds__(512) void conv_halo_fwd_kernel(ConvArgs a) {
     char* sW = smem;                                    // [2][WBUF]
     char* sH = smem + 2 * WBUF;                         // halo [(TH+R-1)*(TW+S-1)][128 B]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar
     const int HWd = HALO_TW + a.S - 1, HHd = HALO_TH + a.R - 1, HP = HHd * HWd;
     const int tilesW = a.W / HALO_TW, tilesH = a.H / HALO_TH;
     int b = blockIdx.x;
@@ -1116,7 +1116,7 @@ __global__ __launch_bounds__(512) void conv_halo_wgrad_kernel(WgradArgs a, int n
     char* sD = smem;                                    // [512 px][DPITCH]
     char* sH = smem + 512 * DPITCH;                     // halo
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar
     const int HWd = HALO_TW + a.S - 1, HHd = HALO_TH + a.R - 1, HP = HHd * HWd;
     const int tilesW = a.W / HALO_TW, tilesH = a.H / HALO_TH;
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
@@ -1260,7 +1260,7 @@ __global__ __launch_bounds__(512) void conv_halo_narrow_in_kernel(ConvArgs a, in
     const int wpitch = ((ksteps * 4) | 1) * 16;         // odd chunk count per row: conflict-free fragment reads
     char* sW = smem;                                    // [64][wpitch]
     char* sH = smem + DCH * wpitch;                     // halo [(TH+R-1)*(TW+S-1)][PXB]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar
     const int HWd = HALO_TW + a.S - 1, HHd = HALO_TH + a.R - 1, HP = HHd * HWd;
     const int tilesW = a.W / HALO_TW, tilesH = a.H / HALO_TH;
     const int frow = lane & 15, fq = lane >> 4;
@@ -1443,7 +1443,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     char* sX = smem;                       // [2][BKP][XP]
     char* sD = smem + 2 * BKP * XP;        // [2][BKP][DP]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar
     const int wm = wave / WGN, wn = wave % WGN;
     const int Mrows = a.R * a.S * a.C;
     const int m0 = blockIdx.x * BMW, n0 = blockIdx.y * BNW;
@@ -1616,7 +1616,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_glds_kernel(WgradArgs a) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages of { X [BKP][PITCH], DY [BKP][PITCH] }
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar
     const int wm = wave >> 2, wn = wave & 3;
     const int Mrows = a.R * a.S * a.C;
     // 1-D grid, XCD-aware: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous range of logical ids
@@ -2022,6 +2022,194 @@ static int run_gemm(const sgg_conv_desc* d, ConvArgs a, void* ws, size_t ws_byte
     return sgg_check_launch();
 }
 
+// -------------------------------------------------------------------------------------------------
+// 3x3 stride-1 weight gradient with the x HALO resident in LDS and ALL 9 TAPS accumulated by one block (the residual
+// blocks' convs, module.py:210-216 backward).
+//
+// conv_wgrad_glds_kernel gives every tap its own block, so a stage streams 32 KB of x and 32 KB of dy per 8.4 MFLOP
+// and the kernel is bound by that L2->LDS stream, not by the MFMAs.  Here a block owns
+// dW[9 taps][64 c][128 k] (36 MFMA tiles per wave: 9 taps x 4 cout tiles of its 16-channel slice) and walks pixel
+// tiles of 2 rows x 64 columns: per stage the 4 x 66 halo pixels of its 64 input channels (36 KB) serve all nine taps
+// as shifted rows, next to a [128 px][128 k] dy tile (32 KB) -- 68 KB per 18.9 MFLOP, 2.1x the FLOP per staged byte.
+// Operands are transposed on the fly with ds_read_b64_tr_b16 as in conv_wgrad_glds_kernel; dy keeps that kernel's
+// swizzle (256-byte rows), the 128-byte halo rows use w9_xkey (below), conflict-free for any tap shift.
+// Pixel tiles are split over `splits` blocks per output tile; slabs are summed in fixed order by wgrad_reduce_kernel.
+// -------------------------------------------------------------------------------------------------
+#define W9_TW 64
+#define W9_PITCH 72                                    // halo row pitch in pixels (66 used; multiple of 8 = one DMA)
+#define W9_XBYTES (4 * W9_PITCH * 128)
+#define W9_DBYTES (128 * 256)
+#define W9_STAGE (W9_XBYTES + W9_DBYTES)
+
+struct W9Args {
+    const char* x;       // (N,H,W,C)
+    const char* dy;      // (N,H,W,K)
+    float* ws;           // [splits][9*C][K] f32 slabs
+    int N, H, W, C, K, reflect;
+    int tiles, tiles_per_split;
+};
+
+// 16-byte chunk XOR key of halo row `row` (128-byte rows, two per 256-byte bank line): a transposing read touches rows
+// {b..b+3, b+8..b+11} per 32-lane group; bits 0, 1 and 3 of the row index tell those eight apart for every b, bit 0
+// already selects the half line, bits 1 and 3 pick one of the four 32-byte column pairs.
+__device__ inline int w9_xkey(int row) { return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1; }
+
+__global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages of { X halo [4][72][128 B], DY [128][256 B] }
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar
+    const int ct = wave & 3, kh = wave >> 2;             // wave: 16-channel slice of the 64, 64-cout half of the 128
+    const int ktiles = a.K >> 7, otiles = (a.C >> 6) * ktiles;
+    int lid;
+    {
+        const int b = (int)blockIdx.x, nm = (int)gridDim.x;
+        const int q = nm >> 3, rr = nm & 7, xcd = b & 7;
+        lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
+    }
+    const int split = lid / otiles, tl = lid - split * otiles;
+    const int c0 = (tl / ktiles) * 64, n0 = (tl % ktiles) * 128;
+    const int t_beg = split * a.tiles_per_split;
+    const int t_end = min(a.tiles, t_beg + a.tiles_per_split);
+    const int tilesW = a.W / W9_TW, tilesH = a.H >> 1;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+    auto stage_tile = [&](int stg, int t) {
+        const int tw = t % tilesW, rest = t / tilesW;
+        const int th = rest % tilesH, n = rest / tilesH;
+        const int h0 = th * 2, w0 = tw * W9_TW;
+        char* sX = smem + stg * W9_STAGE;
+        char* sD = sX + W9_XBYTES;
+        // dy: 32 wave-instructions of 4 pixels x 256 B; wave w issues 4w..4w+3
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = wave * 4 + i;
+            const int px = d * 4 + (lane >> 4), pos = lane & 15;
+            const int key = wg2_key<bf16>(px) & 15;
+            const int trow = px >> 6, tcol = px & 63;
+            const char* src = a.dy + ((((size_t)n * a.H + h0 + trow) * a.W + w0 + tcol) * a.K + n0) * 2 + ((pos ^ key) << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sD + d * 1024), 16, 0, 0);
+        }
+        // x halo: 36 wave-instructions of 8 pixels x 128 B (row k = q / 9, column group q % 9); wave w issues w, w+8, ...
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int q = wave + 8 * i;
+            if (q >= 36) break;
+            const int k = q / 9, cg = q - 9 * k;
+            const int hp = cg * 8 + (lane >> 3), pos = lane & 7;
+            const int key = w9_xkey(k * W9_PITCH + hp);
+            int hi = h0 - 1 + k, wi = w0 - 1 + hp;
+            bool ok = hp < W9_TW + 2;
+            if (a.reflect) {
+                hi = hi < 0 ? -hi : (hi >= a.H ? 2 * (a.H - 1) - hi : hi);
+                wi = wi < 0 ? -wi : (wi >= a.W ? 2 * (a.W - 1) - wi : wi);
+            } else ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            const char* src = ok ? a.x + ((((size_t)n * a.H + hi) * a.W + wi) * a.C + c0) * 2 + ((pos ^ key) << 4) : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sX + (k * W9_PITCH + cg * 8) * 128), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, u = lane & 15, q4 = u >> 2, pp = u & 3;
+    // Fragment addresses = stage base + compile-time constant + lane part.  The swizzle keys depend on the low 4 bits of
+    // the row index only: for dy that is the lane's row within the 32-pixel step; for the halo it is (b + lane row) mod 16
+    // with b mod 16 = 8 * (halo row parity) + tap column, i.e. six classes.
+    int doff[4][2], xoff[6][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int L = 8 * g + q4 + 4 * h;
+        const int kd = wg2_key<bf16>(L) & 15;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int col = kh * 64 + kt * 16 + 4 * pp;
+            doff[kt][h] = L * 256 + (((col >> 3) ^ kd) << 4) + (col & 7) * 2;
+        }
+#pragma unroll
+        for (int cls = 0; cls < 6; ++cls) {
+            const int bl = (cls / 3) * 8 + (cls % 3);
+            const int col = ct * 16 + 4 * pp;
+            xoff[cls][h] = L * 128 + (((col >> 3) ^ w9_xkey(bl + L)) << 4) + (col & 7) * 2;
+        }
+    }
+    if (t_beg < t_end) stage_tile(0, t_beg);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int t = t_beg; t < t_end; ++t) {
+        const int cur = (t - t_beg) & 1;
+        if (t + 1 < t_end) stage_tile(cur ^ 1, t + 1);
+        const char* bX = smem + cur * W9_STAGE;
+        const char* bD = bX + W9_XBYTES;
+        // lane-varying address parts are precomputed (xoff / doff); what changes per fragment is a compile-time constant
+        auto ldD = [&](int kk, int kt) -> bf16x8 {      // dy fragment: 32 pixels of k32-step kk x 16 couts
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bD + kk * (32 * 256) + doff[kt][0]));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bD + kk * (32 * 256) + doff[kt][1]));
+            return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        auto ldX = [&](int kk, int tap) -> bf16x8 {     // x fragment of tap (r, s): the same 32 pixels shifted in the halo
+            const int r = tap / 3, sx = tap - 3 * r;
+            const int b = ((kk >> 1) + r) * W9_PITCH + (kk & 1) * 32 + sx;       // first halo row of the fragment
+            const int cls = ((((kk >> 1) + r) & 1) * 3) + sx;                     // b mod 16 = 8 * parity + sx
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bX + b * 128 + xoff[cls][0]));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bX + b * 128 + xoff[cls][1]));
+            return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        // 36 steps (k32-step kk, tap) of 4 MFMAs; x fragments rotate through 3 registers sets and are fetched two steps
+        // (128 MFMA cycles) ahead, the dy fragments of the next k32-step during the last taps of the current one
+        bf16x8 fd[2][4], fx[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fd[0][j] = ldD(0, j);
+        fx[0] = ldX(0, 0);
+        fx[1] = ldX(0, 1);
+#pragma unroll
+        for (int i = 0; i < 36; ++i) {
+            const int kk = i / 9, tap = i - 9 * kk;
+            if (i + 2 < 36) fx[(i + 2) % 3] = ldX((i + 2) / 9, (i + 2) % 9);
+            if (tap >= 4 && tap < 8 && kk < 3) fd[(kk + 1) & 1][tap - 4] = ldD(kk + 1, tap - 4);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[kk & 1][j], fx[i % 3], acc[tap][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // D[row = cout][col = c]: lane (g,u) owns couts 4g..4g+3 of channel u -> one 16-byte store per tile
+    float* slab = a.ws + (size_t)split * 9 * a.C * a.K;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const size_t mr = (size_t)tap * a.C + c0 + ct * 16 + u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = n0 + kh * 64 + j * 16 + g * 4;
+            *reinterpret_cast<f32x4*>(slab + mr * a.K + k) = acc[tap][j];
+        }
+    }
+}
+
+static bool w9_ok(const sgg_conv_desc* d) {
+    static int en = -1;
+    if (en < 0) { const char* e = getenv("SGG_W9"); en = e ? atoi(e) : 1; }
+    if (!en || !use_glds() || d->dtype != SGG_BF16) return false;
+    if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->Ho != d->H || d->Wo != d->W) return false;
+    return d->W % W9_TW == 0 && d->H % 2 == 0 && d->C % 64 == 0 && d->K % 128 == 0;
+}
+static int w9_tiles(const sgg_conv_desc* d) { return d->N * (d->H / 2) * (d->W / W9_TW); }
+static int w9_tiles_per_split(const sgg_conv_desc* d) {
+    const int otiles = (d->C / 64) * (d->K / 128), T = w9_tiles(d);
+    int sp = otiles >= 256 ? 1 : 256 / otiles;
+    if (sp > T) sp = T;
+    if (sp > 64) sp = 64;
+    return (T + sp - 1) / sp;
+}
+static int w9_splits(const sgg_conv_desc* d) { const int tps = w9_tiles_per_split(d); return (w9_tiles(d) + tps - 1) / tps; }
+
 template <typename T, int BMW, int BNW, int WGM>
 static int launch_wgrad_cfg(WgradArgs& a, int splits, hipStream_t s) {
     constexpr size_t lds = 2 * 32 * (BMW + BNW) * sizeof(T);
@@ -2041,6 +2229,7 @@ static bool wgrad_use_v2(const sgg_conv_desc* d) {
 static int wgrad_splits(const sgg_conv_desc* d) {
     int64_t P = (int64_t)d->N * d->Ho * d->Wo;
     if (halo_wgrad_ok(d)) return halo_wgrad_blocks(d);               // one slab per persistent block
+    if (w9_ok(d)) return w9_splits(d);
     if (wgrad_use_v2(d)) {                                         // one 8-wave block per CU: ~256 blocks in all
         int64_t tiles = (int64_t)((d->R * d->S * d->C + 255) / 256) * ((d->K + 255) / 256);
         int64_t sp = 256 / tiles, maxs = (P + 127) / 128;
@@ -2084,6 +2273,26 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
         int blocks0 = (int)((total0 + 255) / 256); if (blocks0 > 4096) blocks0 = 4096;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks0), dim3(256), 0, s, (const float*)ws, dw, d->R * d->S, d->C, d->K, Cr, Kr, nb, accumulate);
         return sgg_check_launch();
+    }
+    if constexpr (sizeof(T) == 2) {
+        if (w9_ok(d)) {                                   // 3x3 s1: x halo resident, all taps per block
+            const int sp = w9_splits(d);
+            size_t need9 = (size_t)sp * 9 * d->C * d->K * sizeof(float);
+            if (ws_bytes < need9 || !ws) return SGG_EWORKSPACE;
+            W9Args w;
+            w.x = (const char*)x; w.dy = (const char*)dy; w.ws = (float*)ws;
+            w.N = d->N; w.H = d->H; w.W = d->W; w.C = d->C; w.K = d->K; w.reflect = d->pad_mode == SGG_PAD_REFLECT;
+            w.tiles = w9_tiles(d); w.tiles_per_split = w9_tiles_per_split(d);
+            static bool attr9 = false;
+            if (!attr9) { hipFuncSetAttribute((const void*)conv3x3_wgrad_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W9_STAGE); attr9 = true; }
+            hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel, dim3((unsigned)(sp * (d->C / 64) * (d->K / 128))), dim3(512), 2 * W9_STAGE, s, w);
+            int rc9 = sgg_check_launch();
+            if (rc9) return rc9;
+            int64_t total9 = (int64_t)9 * Cr * (d->K / 4);
+            int blocks9 = (int)((total9 + 255) / 256); if (blocks9 > 4096) blocks9 = 4096;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks9), dim3(256), 0, s, (const float*)ws, dw, 9, d->C, d->K, Cr, Kr, sp, accumulate);
+            return sgg_check_launch();
+        }
     }
     int splits = wgrad_splits(d);
     a.pix_per_split = (int)align_up((size_t)((a.P + splits - 1) / splits), 64);

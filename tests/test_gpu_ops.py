@@ -71,6 +71,8 @@ CONV_CASES = [
     ("halo3_reflect_chunks", 3, 1, "REFLECT-1", 192, 320, 4, 128),  # 3 / 5 chunks (halo refill schedule), 2 channel tiles
     ("halo3_reflect_wide", 3, 1, "REFLECT-1", 64, 64, 6, 256),    # two column tiles: left / right mirror patches apart
     ("halo3_same_tail", 3, 1, "SAME", 128, 192, 6, 256),          # zero padding fwd + dgrad, column tiles, tails
+    ("w9_reflect", 3, 1, "REFLECT-1", 64, 128, 4, 64),            # all-taps halo wgrad (bf16): one output tile, 4 pixel tiles
+    ("w9_same_multi", 3, 1, "SAME", 128, 256, 6, 128),            # zero padding, 2x2 output tiles, column tiles
 ]
 
 

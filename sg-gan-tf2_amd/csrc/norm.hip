@@ -126,23 +126,26 @@ __global__ __launch_bounds__(256) void in_finalize_bwd_kernel(const float* parti
     }
 }
 
-// dgamma[c] (+)= sum_n sum g*xhat ; dbeta[c] (+)= sum_n sum g   (fixed order over n -> deterministic)
-__global__ void in_param_grad_kernel(const float* tot, float* dgamma, float* dbeta, int C, int N, int Cr, int accumulate) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cr) return;
-    double tg = 0.0, tb = 0.0;
-    for (int n = 0; n < N; ++n) { tb += (double)tot[((size_t)n * C + c) * 2]; tg += (double)tot[((size_t)n * C + c) * 2 + 1]; }
-    dgamma[c] = accumulate ? dgamma[c] + (float)tg : (float)tg;
-    dbeta[c] = accumulate ? dbeta[c] + (float)tb : (float)tb;
+// dgamma[c] (+)= sum_n sum g*xhat ; dbeta[c] (+)= sum_n sum g   (fixed order over n -> deterministic).  Run by the
+// first block of the backward apply kernel (a separate launch cost ~5 us per instance norm for a few hundred FLOPs).
+struct InParamGrad { const float* tot; float* dgamma; float* dbeta; int N, Cr, accumulate; };
+__device__ inline void in_param_grad(const InParamGrad& g, int C) {
+    for (int c = threadIdx.x; c < g.Cr; c += blockDim.x) {
+        double tg = 0.0, tb = 0.0;
+        for (int n = 0; n < g.N; ++n) { tb += (double)g.tot[((size_t)n * C + c) * 2]; tg += (double)g.tot[((size_t)n * C + c) * 2 + 1]; }
+        g.dgamma[c] = g.accumulate ? g.dgamma[c] + (float)tg : (float)tg;
+        g.dbeta[c] = g.accumulate ? g.dbeta[c] + (float)tb : (float)tb;
+    }
 }
 
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void in_apply_kernel(const char* x, const char* dy, const char* residual, const float* gamma,
                                                        const float* beta, const float* stats, const float* sums, char* out,
-                                                       int64_t HW, int C, int rows_per_block, int act, float leak) {
+                                                       int64_t HW, int C, int rows_per_block, int act, float leak, InParamGrad pg) {
     constexpr int VEC = ET<T>::VEC;
     const int CV = C / VEC;
     const int n = blockIdx.y;
+    if (BWD && blockIdx.x == 0 && blockIdx.y == 0) in_param_grad(pg, C);
     const int64_t p0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t p1 = p0 + rows_per_block < HW ? p0 + rows_per_block : HW;
     for (int cvb = 0; cvb < CV; cvb += 256) {
@@ -215,11 +218,11 @@ int sgg_instnorm_fwd(const void* x, const float* gamma, const float* beta, const
     if (dtype == SGG_BF16) {
         hipLaunchKernelGGL((in_partial_kernel<bf16, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
         hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, stats, HW, C, chunks, eps);
-        hipLaunchKernelGGL((in_apply_kernel<bf16, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak);
+        hipLaunchKernelGGL((in_apply_kernel<bf16, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{});
     } else if (dtype == SGG_F32) {
         hipLaunchKernelGGL((in_partial_kernel<float, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
         hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, stats, HW, C, chunks, eps);
-        hipLaunchKernelGGL((in_apply_kernel<float, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak);
+        hipLaunchKernelGGL((in_apply_kernel<float, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{});
     } else return SGG_EINVAL;
     return sgg_check_launch();
 }
@@ -237,16 +240,15 @@ int sgg_instnorm_bwd(const void* dy, const void* x, const float* gamma, const fl
     float* tot = sums + (size_t)N * C * 2;
     int rpb = in_rows_per_block(N, HW, C, 0);
     dim3 gp(chunks, N), ga((unsigned)((HW + rpb - 1) / rpb), N);
+    const InParamGrad pg{tot, dgamma, dbeta, N, C_real, accumulate};
     if (dtype == SGG_BF16) {
         hipLaunchKernelGGL((in_partial_kernel<bf16, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
         hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, sums, tot, HW, C, chunks);
-        hipLaunchKernelGGL(in_param_grad_kernel, dim3((C_real + 63) / 64), dim3(64), 0, s, (const float*)tot, dgamma, dbeta, C, N, C_real, accumulate);
-        hipLaunchKernelGGL((in_apply_kernel<bf16, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak);
+        hipLaunchKernelGGL((in_apply_kernel<bf16, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg);
     } else if (dtype == SGG_F32) {
         hipLaunchKernelGGL((in_partial_kernel<float, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
         hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, sums, tot, HW, C, chunks);
-        hipLaunchKernelGGL(in_param_grad_kernel, dim3((C_real + 63) / 64), dim3(64), 0, s, (const float*)tot, dgamma, dbeta, C, N, C_real, accumulate);
-        hipLaunchKernelGGL((in_apply_kernel<float, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak);
+        hipLaunchKernelGGL((in_apply_kernel<float, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg);
     } else return SGG_EINVAL;
     return sgg_check_launch();
 }

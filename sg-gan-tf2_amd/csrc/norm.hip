@@ -190,6 +190,129 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const char* x, const char
     }
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// Small maps (HW <= IN_FUSED_MAXHW = 512 pixels: the discriminator tail, module.py:296-309; at 2048 pixels the serial
+// walk of a block over its slab is already slower than the split kernels): one block owns a slab of IN_CVB channel
+// vectors of one image and does both passes itself -- statistics, then the apply pass over the same (L2-resident)
+// pixels -- in ONE launch instead of three or four; the split kernels above are launch-latency bound on these
+// (20 us for a 0.5 MB tensor).  Same arithmetic order inside a block every run -> deterministic.
+// -------------------------------------------------------------------------------------------------
+#define IN_CVB 4
+#define IN_FUSED_MAXHW 512
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void in_fused_small_kernel(const char* x, const char* dy, const char* residual, const float* gamma,
+                                                             const float* beta, float* stats, float* tot, char* out,
+                                                             int64_t HW, int C, float eps, int act, float leak) {
+    constexpr int VEC = ET<T>::VEC;
+    constexpr int ROWS = 256 / IN_CVB;
+    const int CV = C / VEC;
+    const int n = blockIdx.y;
+    const int cvl = threadIdx.x % IN_CVB, prow = threadIdx.x / IN_CVB;
+    const int cv = blockIdx.x * IN_CVB + cvl;
+    const bool live = cv < CV;
+    __shared__ float red[256][2 * VEC + 1];
+    __shared__ float sh_a[IN_CVB * VEC], sh_b[IN_CVB * VEC];
+
+    float mu[VEC], rs[VEC], gm[VEC], bt[VEC];
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int c = cv * VEC + e;
+            gm[e] = gamma[c]; bt[e] = beta[c];
+            if (BWD) { mu[e] = stats[((size_t)n * C + c) * 2]; rs[e] = stats[((size_t)n * C + c) * 2 + 1]; }
+        }
+    }
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s1[e] = s2[e] = 0.f;
+    if (live)
+        for (int64_t p = prow; p < HW; p += ROWS) {
+            const size_t off = (((size_t)n * HW + p) * C + (size_t)cv * VEC) * sizeof(T);
+            float xv[VEC];
+            ET<T>::unpack(ld16(x + off), xv);
+            if (!BWD) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { s1[e] += xv[e]; s2[e] += xv[e] * xv[e]; }
+            } else {
+                float gv[VEC];
+                ET<T>::unpack(ld16(dy + off), gv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float xh = (xv[e] - mu[e]) * rs[e];
+                    const float g = gv[e] * act_grad_from_pre(gm[e] * xh + bt[e], act, leak);
+                    s1[e] += g; s2[e] += g * xh;
+                }
+            }
+        }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][VEC + e] = s2[e]; }
+    __syncthreads();
+    if (threadIdx.x < IN_CVB * VEC) {                    // fixed-order combine over the pixel rows, in f64
+        const int l = threadIdx.x / VEC, e = threadIdx.x % VEC;
+        double a = 0.0, b = 0.0;
+        for (int r = 0; r < ROWS; ++r) { a += (double)red[r * IN_CVB + l][e]; b += (double)red[r * IN_CVB + l][VEC + e]; }
+        const int c = (blockIdx.x * IN_CVB + l) * VEC + e;
+        if (c < C) {
+            const size_t i = ((size_t)n * C + c) * 2;
+            if (!BWD) {
+                const double mean = a / (double)HW;
+                double var = b / (double)HW - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)eps));
+                stats[i] = mf; stats[i + 1] = rf;
+                sh_a[threadIdx.x] = mf; sh_b[threadIdx.x] = rf;
+            } else {
+                tot[i] = (float)a; tot[i + 1] = (float)b;
+                sh_a[threadIdx.x] = (float)(a / (double)HW); sh_b[threadIdx.x] = (float)(b / (double)HW);
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    float A[VEC], B[VEC], m1[VEC], m2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        if (!BWD) { mu[e] = sh_a[cvl * VEC + e]; rs[e] = sh_b[cvl * VEC + e]; }
+        else { m1[e] = sh_a[cvl * VEC + e]; m2[e] = sh_b[cvl * VEC + e]; }
+        A[e] = gm[e] * rs[e]; B[e] = bt[e] - mu[e] * A[e];
+    }
+    for (int64_t p = prow; p < HW; p += ROWS) {
+        const size_t off = (((size_t)n * HW + p) * C + (size_t)cv * VEC) * sizeof(T);
+        float xv[VEC], o[VEC];
+        ET<T>::unpack(ld16(x + off), xv);
+        if (!BWD) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = act_apply(xv[e] * A[e] + B[e], act, leak);
+            if (residual) {
+                float rv[VEC];
+                ET<T>::unpack(ld16(residual + off), rv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] += rv[e];
+            }
+        } else {
+            float gv[VEC];
+            ET<T>::unpack(ld16(dy + off), gv);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xh = (xv[e] - mu[e]) * rs[e];
+                const float g = gv[e] * act_grad_from_pre(gm[e] * xh + bt[e], act, leak);
+                o[e] = A[e] * (g - m1[e] - xh * m2[e]);
+            }
+        }
+        st16(out + off, ET<T>::pack(o));
+    }
+}
+
+__global__ void in_param_grad_kernel(InParamGrad g, int C) { in_param_grad(g, C); }
+
+static bool in_use_fused(int64_t HW) {
+    static int mx = -1;
+    if (mx < 0) { const char* e = getenv("SGG_IN_FUSED_MAXHW"); mx = e ? atoi(e) : IN_FUSED_MAXHW; }
+    return HW <= mx;
+}
+
 static int in_rows_per_block(int N, int64_t HW, int C, int vec) {
     // aim for >= 2048 blocks of >= 64 pixels
     int64_t r = HW * N / 2048;
@@ -211,6 +334,14 @@ int sgg_instnorm_fwd(const void* x, const float* gamma, const float* beta, const
     if (act == SGG_ACT_TANH) return SGG_EUNSUPPORTED;
     if (!ws || ws_bytes < sgg_instnorm_workspace(N, HW, C)) return SGG_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype != SGG_BF16 && dtype != SGG_F32) return SGG_EINVAL;
+    if (in_use_fused(HW)) {
+        const int vec = dtype == SGG_BF16 ? 8 : 4;
+        dim3 gf((unsigned)((C / vec + IN_CVB - 1) / IN_CVB), N);
+        if (dtype == SGG_BF16) hipLaunchKernelGGL((in_fused_small_kernel<bf16, false>), gf, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, eps, act, leak);
+        else hipLaunchKernelGGL((in_fused_small_kernel<float, false>), gf, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, eps, act, leak);
+        return sgg_check_launch();
+    }
     int chunks = in_chunks(HW);
     float* partial = (float*)ws;
     int rpb = in_rows_per_block(N, HW, C, 0);
@@ -241,6 +372,15 @@ int sgg_instnorm_bwd(const void* dy, const void* x, const float* gamma, const fl
     int rpb = in_rows_per_block(N, HW, C, 0);
     dim3 gp(chunks, N), ga((unsigned)((HW + rpb - 1) / rpb), N);
     const InParamGrad pg{tot, dgamma, dbeta, N, C_real, accumulate};
+    if (dtype != SGG_BF16 && dtype != SGG_F32) return SGG_EINVAL;
+    if (in_use_fused(HW)) {
+        const int vec = dtype == SGG_BF16 ? 8 : 4;
+        dim3 gf((unsigned)((C / vec + IN_CVB - 1) / IN_CVB), N);
+        if (dtype == SGG_BF16) hipLaunchKernelGGL((in_fused_small_kernel<bf16, true>), gf, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, (float*)stats, tot, (char*)dx, HW, C, 0.f, act, leak);
+        else hipLaunchKernelGGL((in_fused_small_kernel<float, true>), gf, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, (float*)stats, tot, (char*)dx, HW, C, 0.f, act, leak);
+        hipLaunchKernelGGL(in_param_grad_kernel, dim3(1), dim3(256), 0, s, pg, C);
+        return sgg_check_launch();
+    }
     if (dtype == SGG_BF16) {
         hipLaunchKernelGGL((in_partial_kernel<bf16, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
         hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, sums, tot, HW, C, chunks);

@@ -887,6 +887,212 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// 3x3 STRIDE-2 data gradient / Conv2DTranspose forward with the dy halo resident in LDS and all four output-parity
+// classes computed by one block (module.py:230-236 backward, :254-258 forward; D's module.py:284-294 backward).
+//
+// The generic kernel gives every parity class its own blocks with 128x64 tiles: K loops of 2-8 tiles, 43 FLOP per staged
+// byte, and every dy pixel fetched once per tap.  Here a block owns an 8 x 32 tile of dy pixels = a 16 x 64 tile of
+// output pixels x 64 output channels: per 64-channel chunk of dy the 10 x 34 halo is staged once (double-buffered
+// across chunks) and the nine taps -- 4 + 2 + 2 + 1 over the classes -- read shifted rows of it; weights stream per
+// kernel row (3 taps, 24 KB) through a 2-stage ring.  3.6x fewer L2->LDS bytes, no per-class prologue.
+// Wave w owns dy row w of the tile (two 16-pixel fragments) x all 64 channels x 4 classes = 32 MFMA tiles.
+// Output pixel (2i+a, 2j+b) of class (a,b) takes tap (r,s) with a = (r+pad_t)&1, b = (s+pad_l)&1 from dy pixel
+// (i + (a+pad_t-r)/2, j + (b+pad_l-s)/2), zero outside dy.
+// -------------------------------------------------------------------------------------------------
+#define S2_TI 8
+#define S2_TJ 32
+#define S2_PITCH 40                                    // halo row pitch in pixels (34 used)
+#define S2_HALO_BYTES ((S2_TI + 2) * S2_PITCH * 128)   // 51200
+#define S2_WSTAGE (3 * 64 * 128)                       // one kernel row of taps x 64 output channels x 128 B
+#define S2_LDS (2 * S2_HALO_BYTES + 2 * S2_WSTAGE)     // 151552
+
+template <int PT, int PL>                             // pad_t, pad_l (0 or 1): compile-time so that each tap's class is static
+__global__ __launch_bounds__(512) void deconv_s2_halo_kernel(ConvArgs a, int total_tiles, int tiles_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sH = smem;                                   // 2 x halo [10][40][128 B]
+    char* sW = smem + 2 * S2_HALO_BYTES;               // 2 x [3 taps][64 c][128 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int SC = a.K, DC = a.C;                      // dy channels (reduction), dx channels
+    const int wrow = 9 * SC, nchunk = SC >> 6;
+    const int tilesN = DC >> 6, tilesJ = a.Wo / S2_TJ, tilesI = a.Ho / S2_TI;
+    // Persistent blocks: block `lid` (XCD-contiguous numbering) walks tiles lid*tiles_per_block ... in order, so the
+    // prologue of a tile (halo + first weights) is fetched under the last stage of the previous one and the output
+    // stores of a tile drain under the next tile's MFMAs; consecutive tiles share halo columns (L2 hits).
+    int lid;
+    {
+        const int b = (int)blockIdx.x, nm = (int)gridDim.x;
+        const int q = nm >> 3, rr = nm & 7, xcd = b & 7;
+        lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
+    }
+    const int t_beg = lid * tiles_per_block;
+    const int t_end = min(total_tiles, t_beg + tiles_per_block);
+    if (t_beg >= t_end) return;
+    struct Tile { int img, i0, j0, n0; };
+    auto decode = [&](int t) {
+        Tile T;
+        T.n0 = (t % tilesN) * 64;
+        int mt = t / tilesN;
+        T.j0 = (mt % tilesJ) * S2_TJ; mt /= tilesJ;
+        T.i0 = (mt % tilesI) * S2_TI;
+        T.img = mt / tilesI;
+        return T;
+    };
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    const int hpos = lane & 7, hsub = lane >> 3;
+
+    // halo of one 64-channel chunk: 10 rows x 5 DMAs of 8 pixels; wave w issues q = w, w+8, ...
+    auto load_halo = [&](int buf, const Tile& T, int chunk) {
+        char* dstb = sH + buf * S2_HALO_BYTES;
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int q = wave + 8 * it;
+            if (q >= (S2_TI + 2) * 5) break;
+            const int k = q / 5, cg = q - 5 * k;
+            const int hp = cg * 8 + hsub;
+            const int hi = T.i0 - 1 + k, wi = T.j0 - 1 + hp;
+            const bool ok = hp < S2_TJ + 2 && (unsigned)hi < (unsigned)a.Ho && (unsigned)wi < (unsigned)a.Wo;
+            const int key = ((k * S2_PITCH + hp) >> 1) & 7;
+            const char* src = ok ? a.src + ((((size_t)T.img * a.Ho + hi) * a.Wo + wi) * SC + chunk * 64) * 2 + ((hpos ^ key) << 4) : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dstb + (k * S2_PITCH + cg * 8) * 128), 16, 0, 0);
+        }
+    };
+    // weights of kernel row r, chunk: 3 taps x 64 rows x 128 B = 24 DMAs of 8 rows; wave w issues 3w..3w+2
+    auto load_w = [&](int stg, const Tile& T, int chunk, int r) {
+        char* dstb = sW + stg * S2_WSTAGE;
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int q = wave * 3 + it;                // 0..23: tap column s = q / 8, rows 8*(q%8)..
+            const int sx = q >> 3, row = (q & 7) * 8 + hsub;
+            const int key = (((sx * 64 + row) >> 1) & 7);
+            const char* src = a.wmat + ((size_t)(T.n0 + row) * wrow + (size_t)(r * 3 + sx) * SC + chunk * 64) * 2 + ((hpos ^ key) << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dstb + q * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][2][4];                                // [class][pixel fragment][channel tile]
+    const int frow = lane & 15, fq = lane >> 4;
+    Tile cur = decode(t_beg);
+    load_halo(0, cur, 0);
+    load_w(0, cur, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const int nqc = (t_end - t_beg) * nchunk;          // (tile, chunk) pairs of this block
+    int chunk = 0, tcur = t_beg;
+    for (int qc = 0; qc < nqc; ++qc) {
+        if (chunk == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[c][j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // the (tile, chunk) after this one
+        const bool more = qc + 1 < nqc;
+        const bool last_chunk = chunk + 1 == nchunk;
+        const Tile nxt = (more && last_chunk) ? decode(tcur + 1) : cur;
+        const int nchk = last_chunk ? 0 : chunk + 1;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int st = qc * 3 + r;
+            if (r < 2) load_w((st + 1) & 1, cur, chunk, r + 1);
+            else if (more) load_w((st + 1) & 1, nxt, nchk, 0);
+            if (r == 0 && more) load_halo((qc + 1) & 1, nxt, nchk);     // that buffer was last read in pair qc-1
+            const int ar = (r + PT) & 1, dr = (ar + PT - r) / 2;          // class row parity, dy row offset (compile time)
+            const char* hb = sH + (qc & 1) * S2_HALO_BYTES;
+            const char* wb = sW + (st & 1) * S2_WSTAGE;
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) {
+                const int bs = (sx + PL) & 1, ds = (bs + PL - sx) / 2;
+                const int cls = ar * 2 + bs;
+                const int hrow = (wave + dr + 1) * S2_PITCH + (ds + 1) + frow;   // halo pixel of fragment 0, this lane
+                const int fswP = (hrow >> 1) & 7;
+                const char* bP = hb + hrow * 128;
+                const int wr = sx * 64 + frow;
+                const int fswQ = (wr >> 1) & 7;
+                const char* bQ = wb + wr * 128;
+                u32x4 fw[2][4], fp[2][2];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fw[kk][i] = ld16(bQ + i * 16 * 128 + (((fq + 4 * kk) ^ fswQ) << 4));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fp[kk][j] = ld16(bP + j * 16 * 128 + (((fq + 4 * kk) ^ fswP) << 4));
+                }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[cls][j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[kk][i]),
+                                                                                      __builtin_bit_cast(bf16x8, fp[kk][j]), acc[cls][j][i], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (last_chunk) {
+            // epilogue of tile `cur`; the stores drain while the next tile is multiplied
+            float bv[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[i][e] = a.bias ? a.bias[cur.n0 + i * 16 + fq * 4 + e] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int h = 2 * (cur.i0 + wave) + (c >> 1);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int w = 2 * (cur.j0 + j * 16 + frow) + (c & 1);
+                    const size_t dpix = ((size_t)cur.img * a.H + h) * a.W + w;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int dc = cur.n0 + i * 16 + fq * 4;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[c][j][i][e] + bv[i][e], a.act, a.leak);
+                        if (a.addend) {
+                            const bf16* ad = reinterpret_cast<const bf16*>(a.addend) + dpix * DC + dc;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)ad[e];
+                        }
+                        bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.dst) + dpix * DC + dc) = pk;
+                    }
+                }
+            }
+            cur = nxt; ++tcur; chunk = 0;
+        } else ++chunk;
+    }
+}
+
+static bool s2halo_ok(const ConvArgs& a, bool is_bf16) {
+    static int en = -1;
+    if (en < 0) { const char* e = getenv("SGG_S2HALO"); en = e ? atoi(e) : 1; }
+    if (!en || !is_bf16 || !use_glds() || a.ksplit > 1 || a.ablate || a.reflect) return false;
+    if (a.R != 3 || a.S != 3 || a.stride != 2 || a.H != 2 * a.Ho || a.W != 2 * a.Wo) return false;
+    if (a.pad_t != 0 || a.pad_l != 0) return false;     // TF 'SAME' with an even input pads bottom/right only
+    return a.K % 64 == 0 && a.C % 64 == 0 && a.Wo % S2_TJ == 0 && a.Ho % S2_TI == 0;
+}
+
+template <int PT, int PL>
+static int launch_s2halo_p(const ConvArgs& a, hipStream_t s) {
+    auto kern = deconv_s2_halo_kernel<PT, PL>;
+    static bool attr_done = false;
+    if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS); attr_done = true; }
+    const int total = (int)((int64_t)a.N * (a.Ho / S2_TI) * (a.Wo / S2_TJ) * (a.C / 64));
+    const int tpb = (total + 255) / 256;               // one persistent block per CU
+    const int blocks = (total + tpb - 1) / tpb;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), S2_LDS, s, a, total, tpb);
+    return sgg_check_launch();
+}
+static int launch_s2halo(const ConvArgs& a, hipStream_t s) { return launch_s2halo_p<0, 0>(a, s); }
+
 // shapes the halo-resident kernel takes: 3x3, stride 1, pad 1 on a same-size output, bf16, 64 | source channels,
 // 128 | W, even H; REFLECT only forward (the REFLECT data gradient needs the mirrored border terms)
 static bool halo3_ok(const ConvArgs& a, int mode, bool is_bf16) {
@@ -1949,6 +2155,9 @@ static int launch_gemm(const ConvArgs& a, hipStream_t s) {
     } else {
         DC = a.C; classes = a.stride * a.stride;
         Mmax = (int64_t)a.N * ((a.H + a.stride - 1) / a.stride) * ((a.W + a.stride - 1) / a.stride);
+    }
+    if constexpr (MODE == MODE_DGRAD && sizeof(T) == 2) {
+        if (s2halo_ok(a, true)) return launch_s2halo(a, s);
     }
     if constexpr (MODE != MODE_BORDER && sizeof(T) == 2) {
         if (halo3_ok(a, MODE, true)) {

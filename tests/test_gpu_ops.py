@@ -71,6 +71,8 @@ CONV_CASES = [
     ("halo3_reflect_chunks", 3, 1, "REFLECT-1", 192, 320, 4, 128),  # 3 / 5 chunks (halo refill schedule), 2 channel tiles
     ("halo3_reflect_wide", 3, 1, "REFLECT-1", 64, 64, 6, 256),    # two column tiles: left / right mirror patches apart
     ("halo3_same_tail", 3, 1, "SAME", 128, 192, 6, 256),          # zero padding fwd + dgrad, column tiles, tails
+    ("s2halo_c2_like", 3, 2, "SAME", 64, 128, 16, 64),            # stride-2 data gradient, all parity classes per block
+    ("s2halo_c3_like", 3, 2, "SAME", 128, 192, 32, 128),          # two output-channel tiles, 3 dy chunks, 2x2 pixel tiles
     ("w9_reflect", 3, 1, "REFLECT-1", 64, 128, 4, 64),            # all-taps halo wgrad (bf16): one output tile, 4 pixel tiles
     ("w9_same_multi", 3, 1, "SAME", 128, 256, 6, 128),            # zero padding, 2x2 output tiles, column tiles
 ]
@@ -105,7 +107,8 @@ def test_conv2d_fwd_bwd(sg, case, dtype):
     close(tb.grad.detach().cpu().numpy(), vb.g, dtype, "db")
 
 
-DECONV_CASES = [("d1_like", 16, 8, 6, 5), ("d2_like", 24, 16, 4, 8), ("wide", 128, 64, 5, 7), ("odd_c", 8, 3, 3, 3)]
+DECONV_CASES = [("d1_like", 16, 8, 6, 5), ("d2_like", 24, 16, 4, 8), ("wide", 128, 64, 5, 7), ("odd_c", 8, 3, 3, 3),
+                ("s2halo_d2_like", 128, 64, 8, 32), ("s2halo_d1_like", 256, 128, 16, 32)]
 
 
 @pytest.mark.parametrize("dtype", DT, ids=["f32", "bf16"])

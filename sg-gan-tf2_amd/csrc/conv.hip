@@ -1176,7 +1176,7 @@ __global__ __launch_bounds__(256) void fold_halo_gather_kernel(const char* dy, c
 #define HALO_MAXR 7
 
 template <typename T>
-__global__ __launch_bounds__(512) void conv_halo_fwd_kernel(ConvArgs a) {
+__global__ __launch_bounds__(512) void conv_halo_fwd_kernel(ConvArgs a, int flip) {   // flip: weight taps mirrored (data gradient)
     constexpr int VEC = ET<T>::VEC;
     constexpr int ES = (int)sizeof(T);
     constexpr int CCH = 128 / ES;                       // channels per halo pass (one 128-byte LDS row per pixel)
@@ -1223,7 +1223,8 @@ __global__ __launch_bounds__(512) void conv_halo_fwd_kernel(ConvArgs a) {
             const char* src = zero;
             if (row < a.S * 16) {
                 int s = row >> 4, k = row & 15;
-                if (k < a.K) src = a.wmat + ((size_t)k * wrow + (size_t)(r * a.S + s) * a.C + cc * CCH) * ES + lcc * 16;
+                const int tap = flip ? (a.R - 1 - r) * a.S + (a.S - 1 - s) : r * a.S + s;
+                if (k < a.K) src = a.wmat + ((size_t)k * wrow + (size_t)tap * a.C + cc * CCH) * ES + lcc * 16;
             }
             if (base + wave * 8 < a.S * 16)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -1296,14 +1297,26 @@ static bool halo_fwd_ok(const sgg_conv_desc* d) {
 }
 
 template <typename T>
-static int launch_halo_fwd(const sgg_conv_desc* d, const ConvArgs& a, hipStream_t s) {
+static int launch_halo_fwd(const sgg_conv_desc* d, const ConvArgs& a, hipStream_t s, int flip = 0) {
     size_t lds = 2 * (size_t)HALO_MAXR * 16 * 128 + (size_t)(HALO_TH + d->R - 1) * (HALO_TW + d->S - 1) * 128 + 1024;
     auto kern = conv_halo_fwd_kernel<T>;
     static bool attr_done = false;
     if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
     dim3 grid((unsigned)(d->N * (d->H / HALO_TH) * (d->W / HALO_TW)));
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a, flip);
     return sgg_check_launch();
+}
+
+// data gradient of a narrow-INPUT conv (the stem, 3->64 7x7; cycle mode back-propagates into the fake image): as a
+// convolution over dy it is the head's shape (64 -> <= 16 channels), so it runs conv_halo_fwd_kernel with mirrored taps
+// and zero padding; REFLECT's MirrorPadGrad terms are then added to the border pixels by the MODE_BORDER launch
+static bool halo_dgrad_narrow_ok(const sgg_conv_desc* d) {
+    static int en = -1;
+    if (en < 0) { const char* e = getenv("SGG_STEM_DGRAD_HALO"); en = e ? atoi(e) : 1; }
+    const int cch = d->dtype == SGG_BF16 ? 64 : 32;
+    return en && use_glds() && d->C <= 16 && d->stride == 1 && d->R <= HALO_MAXR && d->S <= HALO_MAXR && d->R == d->S &&
+           d->Ho == d->H && d->Wo == d->W && d->pad_t == (d->R - 1) / 2 && d->pad_l == (d->S - 1) / 2 &&
+           d->H % HALO_TH == 0 && d->W % HALO_TW == 0 && d->K % cch == 0;
 }
 
 // Weight gradient of the same narrow-output convolution: dW[(r,s,c)][k] = sum_pixels x~[p,(r,s),c] * dy[p][k] with
@@ -2593,6 +2606,13 @@ int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w, c
         int rc0 = d->dtype == SGG_BF16 ? launch_halo_narrow_in<bf16>(d, a, 1, (hipStream_t)stream) : launch_halo_narrow_in<float>(d, a, 1, (hipStream_t)stream);
         if (rc0 || !a.reflect) return rc0;
         // REFLECT: add the mirrored (MirrorPadGrad) terms of the border pixels with the small register-path launch
+        return d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_BORDER>(a, (hipStream_t)stream) : launch_gemm<float, MODE_BORDER>(a, (hipStream_t)stream);
+    }
+    if (!addend && halo_dgrad_narrow_ok(d)) {
+        ConvArgs h = a;                                  // the same computation written as a forward conv over dy
+        h.C = d->K; h.K = d->C; h.reflect = 0;
+        int rc0 = d->dtype == SGG_BF16 ? launch_halo_fwd<bf16>(d, h, (hipStream_t)stream, 1) : launch_halo_fwd<float>(d, h, (hipStream_t)stream, 1);
+        if (rc0 || !a.reflect) return rc0;
         return d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_BORDER>(a, (hipStream_t)stream) : launch_gemm<float, MODE_BORDER>(a, (hipStream_t)stream);
     }
     const size_t fb = fold_bytes(d);

@@ -35,7 +35,15 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+
+
 def _s():
+    """The current HIP stream of the current device as a raw handle.  torch.cuda.current_stream() builds a Stream
+    object per call (~8 us, 750 launches per step); the raw accessor is one C call."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(_raw_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

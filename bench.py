@@ -130,6 +130,8 @@ class EventProfiler:
                 tag = ("res_conv_wgrad", d.R * d.S * d.C, d.K, d.N * d.Ho * d.Wo)
         elif name == "instnorm_fwd" and len(key) == 4 and key[3] == 256 and tuple(key[1:3]) == self.res_hw:
             tag = ("res_instnorm_fwd", key[0] * key[1] * key[2] * key[3])
+        elif name == "instnorm_fwd_partial" and len(key) == 4 and key[3] == 256 and tuple(key[1:3]) == self.res_hw:
+            tag = ("res_instnorm_fwd_fused_stats", key[0] * key[1] * key[2] * key[3])
         if tag is None:
             return None
         k = self.seen.get(tag, 0)
@@ -307,7 +309,8 @@ def main():
                 fl = 2.0 * tag[1] * tag[2] * tag[3]
                 kt[tag[0]] = {"avg_ms": ms, "launches": n, "tflops": fl / (ms * 1e-3) / 1e12, "gflop_per_launch": fl / 1e9}
             else:
-                by = 3 * tag[1] * (2 if a.dtype == "bf16" else 4)       # 2 reads + 1 write of the tensor
+                passes = 2 if tag[0].endswith("fused_stats") else 3      # fused: statistics came from the conv epilogue
+                by = passes * tag[1] * (2 if a.dtype == "bf16" else 4)  # (1 or 2) reads + 1 write of the tensor
                 kt[tag[0]] = {"avg_ms": ms, "launches": n, "gbs": by / (ms * 1e-3) / 1e9, "mbytes_per_launch": by / 1e6}
         if "res_conv_fwd" in kt:
             k = kt["res_conv_fwd"]
@@ -321,7 +324,9 @@ def main():
             k = kt["res_instnorm_fwd"]
             line["roofline_instnorm"] = {"bound": "hbm", "achieved": k["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                          "frac": k["gbs"] / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": k["avg_ms"],
-                                         "note": "3 launches (partial stats, finalize, apply); algorithmic bytes = 2 reads + 1 write"}
+                                         "note": "unfused instance norm on a (N,H/4,W/4,256) tensor (after the stride-2 conv c3): 3 launches (partial stats, "
+                                                 "finalize, apply); algorithmic bytes = 2 reads + 1 write.  The residual blocks' norms take their "
+                                                 "statistics from the conv epilogue (kernels.res_instnorm_fwd_fused_stats: finalize + apply)"}
         line["kernels"] = kt
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_cycle(a.height, a.width, 19) if a.mode == "cycle" else cpu_baseline(a.height, a.width, 19)

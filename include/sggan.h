@@ -70,6 +70,15 @@ int sgg_pack_conv_weights(const float* w_hwio, int R, int S, int C, int K, int C
 size_t sgg_conv2d_fwd_workspace(const sgg_conv_desc* d);
 int sgg_conv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
                    void* y, int act, float leak, void* ws, size_t ws_bytes, void* stream);
+
+/* conv2d forward that also emits, for the instance norm that follows it (module.py:211-212 etc.), the per-image
+ * per-channel (sum, sum of squares) of the stored output, split over pixel chunks:
+ *   partial[N][chunks][Kpad][2] f32,  chunks = sgg_conv2d_fwd_stats_chunks(d)  (0: this shape has no such epilogue;
+ *   currently the bf16 3x3 stride-1 kernel).  No activation (the norm applies it).  Feed partial to
+ *   sgg_instnorm_fwd_partial(), which then skips its own statistics pass over the tensor. */
+size_t sgg_conv2d_fwd_stats_chunks(const sgg_conv_desc* d);
+int sgg_conv2d_fwd_stats(const sgg_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y,
+                         float* partial, void* ws, size_t ws_bytes, void* stream);
 /* bwd_data: dx = conv^T(dy) including the MirrorPadGrad fold for REFLECT (gen_tape.gradient, model.py:196).
  * ws: sgg_conv2d_bwd_data_workspace() bytes (REFLECT: pre-folded gather rows of the border pixels; small outputs: split-K slabs). */
 size_t sgg_conv2d_bwd_data_workspace(const sgg_conv_desc* d);
@@ -110,6 +119,10 @@ size_t sgg_instnorm_workspace(int N, int64_t HW, int C);
 int sgg_instnorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* y,
                      float* stats, int N, int64_t HW, int C, float eps, int act, float leak, int dtype,
                      void* ws, size_t ws_bytes, void* stream);
+/* same, with the statistics pass replaced by precomputed partial sums partial[N][chunks][C][2] (sgg_conv2d_fwd_stats) */
+int sgg_instnorm_fwd_partial(const void* x, const float* gamma, const float* beta, const void* residual, void* y,
+                             float* stats, const float* partial, int chunks, int N, int64_t HW, int C, float eps,
+                             int act, float leak, int dtype, void* stream);
 /* dx = d/dx of the above given dy (w.r.t. the post-activation output); dgamma/dbeta[C_real] f32 overwritten or
  * (accumulate=1) added to.  gamma/beta/stats are indexed over the padded C. */
 int sgg_instnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats,

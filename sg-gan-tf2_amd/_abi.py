@@ -34,6 +34,8 @@ SIGNATURES = {
     "sgg_pack_conv_weights": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sgg_conv2d_fwd_workspace": (_sz, [_dp]),
     "sgg_conv2d_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _i, _f, _vp, _sz, _vp]),
+    "sgg_conv2d_fwd_stats_chunks": (_sz, [_dp]),
+    "sgg_conv2d_fwd_stats": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgg_conv2d_bwd_data_workspace": (_sz, [_dp]),
     "sgg_conv2d_bwd_data": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgg_conv2d_bwd_weight_workspace": (_sz, [_dp]),
@@ -47,6 +49,7 @@ SIGNATURES = {
     "sgg_bias_grad": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sgg_instnorm_workspace": (_sz, [_i, _i64, _i]),
     "sgg_instnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _i, _f, _i, _vp, _sz, _vp]),
+    "sgg_instnorm_fwd_partial": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _f, _i, _f, _i, _vp]),
     "sgg_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "sgg_act_fwd": (_i, [_vp, _vp, _i64, _i, _f, _i, _vp]),
     "sgg_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _f, _i, _vp]),

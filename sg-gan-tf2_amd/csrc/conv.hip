@@ -32,6 +32,8 @@ struct ConvArgs {
     char* dst;           // FWD: y (N,Ho,Wo,K)  DGRAD: dx (N,H,W,C)
     const char* addend;  // optional tensor added to the result (same layout as dst): the skip-connection gradient
     const char* fold;    // REFLECT DGRAD (v2): pre-folded gather rows of the border pixels [pixel][tap][K], else nullptr
+    float* stats;        // halo 3x3 forward only: per-(image, pixel chunk, channel) (sum, sumsq) of the stored output for the
+                         // instance norm that follows, [N][chunks][K][2] f32; nullptr = not wanted
     float* partial;      // split-K (v2): f32 slabs [ksplit][pdst][DC]
     int ksplit;          // 1 = no split
     int ablate;          // timing experiments only (SGG_ABLATE): 1 no in-loop DMA, 2 no LDS reads/MFMAs, 3 = 1 + no barrier,
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
 //   columns: the two pixels per tile row in columns 1 / W-2 read their gather row per tap from a small LDS patch
 //            (2 x 2 x 9 rows per chunk, from a.fold's first part, which holds the complete mirrored sums for those
 //            pixels) through a per-lane address select in the first / last pixel fragment.
-template <int MODE, bool FOLD>
+template <int MODE, bool FOLD, bool STATS = false>
 __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     constexpr int BN = 256, WGM = 2, WGN = 4, WM = 128, WN = 64, MI = 8, NI = 4, BKB = 128, KK = 2;
     constexpr int QA = 4;                              // weight rows per thread per tile (8 waves x 8 rows x 4)
@@ -866,6 +868,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         for (int e = 0; e < 4; ++e) bv[i][e] = (a.bias && dc < DC) ? a.bias[dc + e] : 0.f;
     }
     const size_t prow = ((size_t)img * a.H + h0 + wm) * a.W + w0;
+    float s1[NI][4], s2[NI][4];                       // STATS: this lane's share of sum / sum of squares per channel
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s1[i][e] = s2[i][e] = 0.f;
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
         const size_t dpix = prow + j * 16 + frow;
@@ -883,6 +890,37 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             }
             bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
             *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.dst) + dpix * DC + dc) = pk;
+            if (STATS) {                              // statistics of what was STORED (the values the norm will read)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float vr = (float)pk[e]; s1[i][e] += vr; s2[i][e] += vr * vr; }
+            }
+        }
+    }
+    if (STATS) {
+        // The instance norm that follows needs per-(image, channel) mean / variance: each wave reduces its 128 pixels x
+        // 64 channels here (registers -> 16-lane butterfly, fixed order) and writes one (sum, sumsq) row per channel as
+        // pixel chunk (tile, wave row) of the image, replacing the norm's own first pass over the tensor.
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    s1[i][e] += __shfl_xor(s1[i][e], off);
+                    s2[i][e] += __shfl_xor(s2[i][e], off);
+                }
+            }
+        if (frow == 0) {
+            const int chunks = tilesH * tilesW * 2;
+            const int chunk = (th * tilesW + tw) * 2 + wm;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int dc = n0 + wn * WN + i * 16 + fq * 4;
+                if (dc >= DC) continue;
+                float* o = a.stats + (((size_t)img * chunks + chunk) * DC + dc) * 2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[2 * e] = s1[i][e]; o[2 * e + 1] = s2[i][e]; }
+            }
         }
     }
 }
@@ -1106,9 +1144,9 @@ static bool halo3_ok(const ConvArgs& a, int mode, bool is_bf16) {
     return mode == MODE_FWD || mode == MODE_DGRAD;
 }
 
-template <int MODE, bool FOLD>
+template <int MODE, bool FOLD, bool STATS = false>
 static int launch_halo3(const ConvArgs& a, hipStream_t s) {
-    auto kern = conv3x3_halo_gemm_kernel<MODE, FOLD>;
+    auto kern = conv3x3_halo_gemm_kernel<MODE, FOLD, STATS>;
     constexpr int lds = FOLD ? H3_LDS_FOLD : H3_LDS;
     static bool attr_done = false;
     if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
@@ -2081,7 +2119,7 @@ static bool desc_ok(const sgg_conv_desc* d) {
 
 static ConvArgs make_args(const sgg_conv_desc* d, const void* src, const void* w, const float* bias, void* dst, int act, float leak) {
     ConvArgs a;
-    a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst; a.addend = nullptr; a.fold = nullptr; a.partial = nullptr; a.ksplit = 1; a.pdst = 0;
+    a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst; a.addend = nullptr; a.fold = nullptr; a.stats = nullptr; a.partial = nullptr; a.ksplit = 1; a.pdst = 0;
     { static int ab = -1; if (ab < 0) { const char* e = getenv("SGG_ABLATE"); ab = e ? atoi(e) : 0; } a.ablate = ab; }
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S; a.stride = d->stride;
     a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.reflect = d->pad_mode == SGG_PAD_REFLECT;
@@ -2175,6 +2213,7 @@ static int launch_gemm(const ConvArgs& a, hipStream_t s) {
     if constexpr (MODE != MODE_BORDER && sizeof(T) == 2) {
         if (halo3_ok(a, MODE, true)) {
             if constexpr (MODE == MODE_DGRAD) { if (a.reflect) return launch_halo3<MODE_DGRAD, true>(a, s); }
+            if constexpr (MODE == MODE_FWD) { if (a.stats) return launch_halo3<MODE_FWD, false, true>(a, s); }
             return launch_halo3<MODE, false>(a, s);
         }
     }
@@ -2224,6 +2263,13 @@ static GemmPlan plan_gemm(const sgg_conv_desc* d, int mode) {
         g.ktot_max = (((d->R + st - 1) / st) * ((d->S + st - 1) / st) * (d->K / vec) + 7) / 8;
     }
     g.ksplit = use_glds() ? conv_ksplit(g.Mmax, g.DC, g.classes, g.ktot_max) : 1;
+    if (g.ksplit > 1 && (mode == MODE_FWD || mode == MODE_DGRAD)) {
+        // shapes the halo-resident kernels take are never split (they only occur at sizes that fill the chip; it also
+        // keeps the small parity-test shapes on the same kernels as the full-size layers)
+        ConvArgs a = make_args(d, nullptr, nullptr, nullptr, nullptr, SGG_ACT_NONE, 0.f);
+        const bool bf = d->dtype == SGG_BF16;
+        if (halo3_ok(a, mode, bf) || (mode == MODE_DGRAD && s2halo_ok(a, bf))) g.ksplit = 1;
+    }
     g.ws_bytes = g.ksplit > 1 ? (size_t)g.ksplit * g.pdst * g.DC * sizeof(float) : 0;
     return g;
 }
@@ -2585,6 +2631,23 @@ int sgg_conv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w, const f
         return d->dtype == SGG_BF16 ? launch_halo_fwd<bf16>(d, a, (hipStream_t)stream) : launch_halo_fwd<float>(d, a, (hipStream_t)stream);
     return d->dtype == SGG_BF16 ? run_gemm<bf16, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream)
                                 : run_gemm<float, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// Pixel chunks per image of the (sum, sumsq) rows sgg_conv2d_fwd_stats() emits; 0 = this shape has no such epilogue
+size_t sgg_conv2d_fwd_stats_chunks(const sgg_conv_desc* d) {
+    if (!desc_ok(d) || d->dtype != SGG_BF16) return 0;
+    ConvArgs a = make_args(d, nullptr, nullptr, nullptr, nullptr, SGG_ACT_NONE, 0.f);
+    if (plan_gemm(d, MODE_FWD).ksplit > 1 || !halo3_ok(a, MODE_FWD, true)) return 0;
+    return (size_t)(d->H / 2) * (d->W / H3_TW) * 2;
+}
+
+int sgg_conv2d_fwd_stats(const sgg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* partial,
+                         void* ws, size_t ws_bytes, void* stream) {
+    if (!desc_ok(d) || !x || !w || !y || !partial) return SGG_EINVAL;
+    if (sgg_conv2d_fwd_stats_chunks(d) == 0) return SGG_EUNSUPPORTED;
+    ConvArgs a = make_args(d, x, w, bias, y, SGG_ACT_NONE, 0.f);
+    a.stats = partial;
+    return run_gemm<bf16, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream);
 }
 
 static size_t fold_bytes(const sgg_conv_desc* d) {

@@ -358,6 +358,21 @@ int sgg_instnorm_fwd(const void* x, const float* gamma, const float* beta, const
     return sgg_check_launch();
 }
 
+int sgg_instnorm_fwd_partial(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* stats,
+                             const float* partial, int chunks, int N, int64_t HW, int C, float eps, int act, float leak, int dtype,
+                             void* stream) {
+    if (!x || !gamma || !beta || !y || !stats || !partial || chunks <= 0 || N <= 0 || HW <= 0 || C <= 0 || C % SGG_CPAD) return SGG_EINVAL;
+    if (act == SGG_ACT_TANH) return SGG_EUNSUPPORTED;
+    if (dtype != SGG_BF16 && dtype != SGG_F32) return SGG_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int rpb = in_rows_per_block(N, HW, C, 0);
+    dim3 ga((unsigned)((HW + rpb - 1) / rpb), N);
+    hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, stats, HW, C, chunks, eps);
+    if (dtype == SGG_BF16) hipLaunchKernelGGL((in_apply_kernel<bf16, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{});
+    else hipLaunchKernelGGL((in_apply_kernel<float, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{});
+    return sgg_check_launch();
+}
+
 int sgg_instnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
                      float* dgamma, float* dbeta, int N, int64_t HW, int C, int C_real, int accumulate, int act, float leak,
                      int dtype, void* ws, size_t ws_bytes, void* stream) {

@@ -78,12 +78,14 @@ def same_pads(n_in: int, k: int, s: int):
 
 class ConvGeom:
     """Geometry of one Conv2D / Conv2DTranspose call site, resolved to an sgg_conv_desc."""
-    __slots__ = ("desc", "x_shape", "y_shape", "ws_wgrad", "ws_dgrad", "ws_fwd", "dtype", "is_deconv")
+    __slots__ = ("desc", "x_shape", "y_shape", "ws_wgrad", "ws_dgrad", "ws_fwd", "dtype", "is_deconv", "stats_chunks")
 
     def __init__(self, desc, x_shape, y_shape, dtype, is_deconv):
         self.desc, self.x_shape, self.y_shape, self.dtype, self.is_deconv = desc, x_shape, y_shape, dtype, is_deconv
         self.ws_wgrad = int(A.lib().sgg_conv2d_bwd_weight_workspace(C.byref(desc)))
         L = A.lib()
+        # pixel chunks of the (sum, sumsq) rows the forward conv can emit for a following instance norm (0: it cannot)
+        self.stats_chunks = 0 if is_deconv else int(L.sgg_conv2d_fwd_stats_chunks(C.byref(desc)))
         # workspaces of the two GEMM directions; a deconv runs the conv's data-gradient kernel forwards
         self.ws_fwd = int((L.sgg_deconv2d_fwd_workspace if is_deconv else L.sgg_conv2d_fwd_workspace)(C.byref(desc)))
         self.ws_dgrad = int((L.sgg_deconv2d_bwd_data_workspace if is_deconv else L.sgg_conv2d_bwd_data_workspace)(C.byref(desc)))
@@ -146,6 +148,19 @@ def conv_fwd(g: ConvGeom, x, w_fwd, bias, act=A.ACT_NONE, leak=0.0):
     A.check(A.lib().sgg_conv2d_fwd(C.byref(g.desc), _p(x), _p(w_fwd), _p(bias), _p(y), act, leak, _p(ws), g.ws_fwd, _s()), "conv2d_fwd")
     if pr: pr.stop()
     return y
+
+
+def conv_fwd_stats(g: ConvGeom, x, w_fwd, bias):
+    """conv forward (no activation) + the per-chunk (sum, sumsq) rows of its output for the instance norm that follows."""
+    assert tuple(x.shape) == g.x_shape and not g.is_deconv and g.stats_chunks > 0
+    y = torch.empty(g.y_shape, dtype=x.dtype, device=x.device)
+    partial = torch.empty((g.y_shape[0], g.stats_chunks, g.y_shape[3], 2), dtype=torch.float32, device=x.device)
+    pr = _prof("conv2d_fwd", g)
+    if pr: pr.start()
+    ws = workspace(g.ws_fwd, x.device) if g.ws_fwd else None
+    A.check(A.lib().sgg_conv2d_fwd_stats(C.byref(g.desc), _p(x), _p(w_fwd), _p(bias), _p(y), _p(partial), _p(ws), g.ws_fwd, _s()), "conv2d_fwd_stats")
+    if pr: pr.stop()
+    return y, partial
 
 
 def conv_dgrad(g: ConvGeom, dy, w_dgrad, addend=None):
@@ -216,6 +231,20 @@ def instnorm_fwd(x, gamma, beta, residual=None, eps=1e-3, act=A.ACT_NONE, leak=0
     if pr: pr.start()
     A.check(A.lib().sgg_instnorm_fwd(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(stats), N, H * W, Cp, eps, act, leak,
                                      dt(x), _p(ws), ws.numel(), _s()), "instnorm_fwd")
+    if pr: pr.stop()
+    return y, stats
+
+
+def instnorm_fwd_partial(x, partial, gamma, beta, residual=None, eps=1e-3, act=A.ACT_NONE, leak=0.0):
+    """instance norm whose statistics pass was done by the producing conv (conv_fwd_stats): finalize + apply only."""
+    N, H, W, Cp = x.shape
+    assert gamma.numel() == Cp and beta.numel() == Cp and partial.shape[0] == N and partial.shape[2] == Cp
+    y = torch.empty_like(x)
+    stats = torch.empty((N, Cp, 2), dtype=torch.float32, device=x.device)
+    pr = _prof("instnorm_fwd_partial", tuple(x.shape))
+    if pr: pr.start()
+    A.check(A.lib().sgg_instnorm_fwd_partial(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(stats), _p(partial), partial.shape[1],
+                                             N, H * W, Cp, eps, act, leak, dt(x), _s()), "instnorm_fwd_partial")
     if pr: pr.stop()
     return y, stats
 

@@ -14,6 +14,8 @@ shape-agnostic, geometry is resolved per call.
 """
 from __future__ import annotations
 
+import os
+
 import math
 
 import numpy as np
@@ -154,6 +156,9 @@ def discriminator_param_specs(df_dim=64, in_c=3, segment_class=34):
 
 
 # ----------------------------------------------------------------------------- layer engine
+FUSE_CONV_IN_STATS = os.environ.get("SGG_FUSE_IN_STATS", "1") != "0"     # A/B switch for the conv -> norm statistics fusion
+
+
 class _ConvUnit:
     """One Conv2D / Conv2DTranspose call site, optionally followed by InstanceNorm (+act, +residual),
     or by a fused activation when there is no norm.  Stateless w.r.t. activations: forward returns a
@@ -195,6 +200,11 @@ class _ConvUnit:
         g = self.geom(x)
         wf, wd = self.packed(x.dtype)
         fused_act = A.ACT_NONE if self.norm else self.act
+        if self.kind == "conv" and self.norm and g.stats_chunks and FUSE_CONV_IN_STATS:
+            # the conv's epilogue emits the norm's per-chunk sums: the norm skips its own pass over the tensor
+            xc, part = K.conv_fwd_stats(g, x, wf, P.p(n + "_b"))
+            y, stats = K.instnorm_fwd_partial(xc, part, P.p(n + "_g"), P.p(n + "_beta"), residual, self.net.eps, self.act, self.leak)
+            return y, (g, x, xc, stats)
         if self.kind == "conv":
             xc = K.conv_fwd(g, x, wf, P.p(n + "_b"), fused_act, self.leak)
         else:

@@ -107,6 +107,38 @@ def test_conv2d_fwd_bwd(sg, case, dtype):
     close(tb.grad.detach().cpu().numpy(), vb.g, dtype, "db")
 
 
+@pytest.mark.parametrize("shape", [(2, 4, 128, 64, 256), (1, 6, 256, 128, 320)], ids=["one_tile_col", "two_tile_cols_ktail"])
+def test_conv_fwd_stats_epilogue(sg, shape):
+    """conv forward + instance-norm statistics epilogue (sgg_conv2d_fwd_stats): the output is bit-identical to the plain
+    forward, the per-chunk (sum, sumsq) rows add up to the sums of the STORED bf16 output, and the norm fed with them
+    matches the norm that makes its own statistics pass."""
+    from sggan_amd import kernels as K, _abi as A
+    N, H, W, Ci, Co = shape
+    rng = np.random.default_rng(3)
+    x = dev(rng.standard_normal((N, H, W, Ci)), torch.bfloat16)
+    w = dev(rng.standard_normal((3, 3, Ci, Co)) / np.sqrt(9 * Ci))
+    b = dev(rng.standard_normal(Co))
+    g = K.conv_geom(N, H, W, Ci, Co, 3, 3, 1, "VALID", 1, torch.bfloat16)
+    assert g.stats_chunks == (H // 2) * (W // 128) * 2
+    wf, _ = K.pack_weights(w, Ci, Co, torch.bfloat16)
+    y0 = K.conv_fwd(g, x, wf, b)
+    y1, part = K.conv_fwd_stats(g, x, wf, b)
+    assert torch.equal(y0, y1)
+    yf = y1.float().cpu().numpy().astype(np.float64)
+    got = part.cpu().numpy().astype(np.float64).sum(axis=1)                   # (N, Co, 2)
+    s1, s2 = yf.sum(axis=(1, 2)), (yf * yf).sum(axis=(1, 2))
+    assert np.abs(got[..., 0] - s1).max() < 1e-4 * max(1.0, np.abs(s1).max()) + 1e-2
+    assert np.abs(got[..., 1] - s2).max() < 1e-4 * s2.max()
+    gam, bet = dev(1 + 0.2 * rng.standard_normal(Co)), dev(0.2 * rng.standard_normal(Co))
+    za, sa = K.instnorm_fwd(y1, gam, bet, None, 1e-3, A.ACT_RELU)
+    zb, sb = K.instnorm_fwd_partial(y1, part, gam, bet, None, 1e-3, A.ACT_RELU)
+    assert (sa - sb).abs().max().item() < 1e-4
+    assert (za.float() - zb.float()).abs().max().item() < 2e-2
+    # shapes without the epilogue report 0 chunks and the entry point refuses them
+    g2 = K.conv_geom(N, 5, 7, Ci, Co, 3, 3, 1, "VALID", 1, torch.bfloat16)
+    assert g2.stats_chunks == 0
+
+
 DECONV_CASES = [("d1_like", 16, 8, 6, 5), ("d2_like", 24, 16, 4, 8), ("wide", 128, 64, 5, 7), ("odd_c", 8, 3, 3, 3),
                 ("s2halo_d2_like", 128, 64, 8, 32), ("s2halo_d1_like", 256, 128, 16, 32)]
 

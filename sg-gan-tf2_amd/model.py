@@ -81,6 +81,7 @@ class sggan(object):
         # use_pool is set (upstream SG-GAN behaviour: D sees a history of fakes)
         self.pool = ImagePool(g("max_size", 50), rng=g("pool_rng", None))
         self.use_pool = bool(g("use_pool", False))
+        self.batch_d_real_fake = bool(g("batch_d_real_fake", True))   # pool mode: D(real) and D(pooled fakes) as one 2N pass
         self.gen_loss_metric, self.disc_loss_metric, self._metric_n = 0.0, 0.0, 0
 
     # ------------------------------------------------------------------ data parallel (new capability)
@@ -176,15 +177,12 @@ class sggan(object):
         cyc_B, t2 = Gab.forward(fake_A)
         DB_fake, tDBf = Db.forward(fake_B, mA)
         DA_fake, tDAf = Da.forward(fake_A, mB)
-        DA_real, tDAr = Da.forward(rA, mA)
-        DB_real, tDBr = Db.forward(rB, mB)
         wA, wB = K.seg_edge_weight(sA, C), K.seg_edge_weight(sB, C)
 
         crit = K.mse_const if self.use_lsgan else K.bce_logits
         gl, dl = self._loss[0:1], self._loss[1:2]
         e = torch.empty_like
         gA_g, gB_g = e(DA_fake), e(DB_fake)                  # d g_loss / d logits
-        dA_r, dA_f, dB_r, dB_f = e(DA_real), e(DA_fake), e(DB_real), e(DB_fake)   # d d_loss / d logits
         crit(DA_fake, 1.0, gl, gA_g)
         crit(DB_fake, 1.0, gl, gB_g, accumulate_loss=True)
         d_cycA, d_cycB = e(cyc_A), e(cyc_B)
@@ -195,24 +193,42 @@ class sggan(object):
         K.gradloss(fake_B, rA, wA, C, gl, d_fB, lam=self.Lg_lambda, accumulate_loss=True)
         # the discriminators judge a HISTORY of fakes when the image pool is on (utils.py:27-53); the pool returns the
         # current fakes until it is full, and then (p = 1/2) older ones, which need their own D forward
-        tDAs, tDBs, DA_fs, DB_fs = tDAf, tDBf, DA_fake, DB_fake
+        pooled_A = pooled_B = False
+        pfA = pfB = smA = smB = None
         if self.use_pool:
-            sA, sB_, smB, smA = self.pool([fake_A, fake_B, mB, mA])       # fake_A is judged on mask_B, fake_B on mask_A
-            if sA is not fake_A:
-                DA_fs, tDAs = Da.forward(sA, smB)
-                dA_f = e(DA_fs)
-            if sB_ is not fake_B:
-                DB_fs, tDBs = Db.forward(sB_, smA)
-                dB_f = e(DB_fs)
-        crit(DA_real, 1.0, dl, dA_r, weight=0.5)
-        crit(DA_fs, 0.0, dl, dA_f, weight=0.5, accumulate_loss=True)
-        crit(DB_real, 1.0, dl, dB_r, weight=0.5, accumulate_loss=True)
-        crit(DB_fs, 0.0, dl, dB_f, weight=0.5, accumulate_loss=True)
+            pfA, pfB, smB, smA = self.pool([fake_A, fake_B, mB, mA])       # fake_A is judged on mask_B, fake_B on mask_A
+            pooled_A, pooled_B = pfA is not fake_A, pfB is not fake_B
+        # D's two loss terms.  When the pool hands back older fakes they need their own D forward anyway: it is run
+        # together with the real batch as ONE pass over 2N images (instance norm is per image, so this is exact) --
+        # half the launches, and D's small tail layers (5x13 ... 1x5 maps) fill more of the chip.
+        def d_loss_pass(Dn, real, m_real, DR, tR, pooled, fakes, m_fakes, DF, tF, first):
+            if pooled and self.batch_d_real_fake:
+                out, tape = Dn.forward(torch.cat([real, fakes]), torch.cat([m_real, m_fakes]))
+                n = real.shape[0]
+                grad = e(out)
+                crit(out[:n], 1.0, dl, grad[:n], weight=0.5, accumulate_loss=not first)
+                crit(out[n:], 0.0, dl, grad[n:], weight=0.5, accumulate_loss=True)
+                Dn.backward(tape, grad)
+                return
+            if pooled:
+                DF, tF = Dn.forward(fakes, m_fakes)
+            g_r, g_f = e(DR), e(DF)
+            crit(DR, 1.0, dl, g_r, weight=0.5, accumulate_loss=not first)
+            crit(DF, 0.0, dl, g_f, weight=0.5, accumulate_loss=True)
+            Dn.backward(tR, g_r); Dn.backward(tF, g_f)
 
         # discriminator gradients (fakes are constants here)
-        Da.backward(tDAr, dA_r); Da.backward(tDAs, dA_f)
+        if pooled_A and self.batch_d_real_fake:
+            d_loss_pass(Da, rA, mA, None, None, True, pfA, smB, None, None, True)
+        else:
+            DA_real, tDAr = Da.forward(rA, mA)
+            d_loss_pass(Da, rA, mA, DA_real, tDAr, pooled_A, pfA if pooled_A else None, smB if pooled_A else None, DA_fake, tDAf, True)
         hDa = self._allreduce(Da)
-        Db.backward(tDBr, dB_r); Db.backward(tDBs, dB_f)
+        if pooled_B and self.batch_d_real_fake:
+            d_loss_pass(Db, rB, mB, None, None, True, pfB, smA, None, None, False)
+        else:
+            DB_real, tDBr = Db.forward(rB, mB)
+            d_loss_pass(Db, rB, mB, DB_real, tDBr, pooled_B, pfB if pooled_B else None, smA if pooled_B else None, DB_fake, tDBf, False)
         hDb = self._allreduce(Db)
         # generator gradients: cycle terms first (they reach the other generator through the fakes)
         d_fB = K.add(d_fB, Gba.backward(t4, d_cycA, want_dx=True))

@@ -8,7 +8,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 root = sys.argv[1]
-MAIN = {"fwd": ("conv3x3_halo_gemm", "conv_gemm_glds"), "dgrad": ("conv3x3_halo_gemm", "conv_gemm_glds"), "wgrad": ("conv_wgrad_glds",)}
+MAIN = {"fwd": ("conv3x3_halo_gemm", "conv_gemm_glds"), "dgrad": ("conv3x3_halo_gemm", "conv_gemm_glds"), "wgrad": ("conv3x3_wgrad_halo", "conv_wgrad_glds")}
 AUX = {"dgrad": ("fold_halo_gather", "fold_gather"), "wgrad": ("wgrad_reduce",)}
 out = {}
 for op in ("fwd", "dgrad", "wgrad"):

@@ -92,6 +92,14 @@ size_t sgg_conv2d_bwd_weight_workspace(const sgg_conv_desc* d);
 int sgg_conv2d_bwd_weight(const sgg_conv_desc* d, const void* x, const void* dy, float* dw_hwio,
                           int C_real, int K_real, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
+/* Weight gradient of TWO applications of one layer in a step (same desc): dw (+)= wgrad(x0, dy0) + wgrad(x1, dy1) with one
+ * launch, one set of split slabs and one reduce (the cycle step applies each generator twice, model.py:120-121 by name).
+ * sgg_conv2d_bwd_weight_pair_supported() tells whether the shape has this path (the all-taps 3x3 stride-1 kernel);
+ * otherwise call sgg_conv2d_bwd_weight twice.  Workspace: sgg_conv2d_bwd_weight_workspace(d). */
+int sgg_conv2d_bwd_weight_pair_supported(const sgg_conv_desc* d);
+int sgg_conv2d_bwd_weight_pair(const sgg_conv_desc* d, const void* x0, const void* dy0, const void* x1, const void* dy1,
+                               float* dw, int C_real, int K_real, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- deconv2d: tf.keras.layers.Conv2DTranspose(3x3, s2, 'same') ---- module.py:254,258
  * `d` describes the EQUIVALENT FORWARD CONV whose input is the deconv OUTPUT:
  *   (d->N,H,W,C) = deconv output, (d->Ho,Wo,K) = deconv input, pad_t/pad_l = TF SAME leading pads of that conv.

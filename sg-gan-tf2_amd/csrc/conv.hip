@@ -2312,9 +2312,11 @@ static int run_gemm(const sgg_conv_desc* d, ConvArgs a, void* ws, size_t ws_byte
 struct W9Args {
     const char* x;       // (N,H,W,C)
     const char* dy;      // (N,H,W,K)
+    const char* x2;      // optional second (x, dy) pair of the same shape: pixel tiles [tiles/2, tiles) read it, so the two
+    const char* dy2;     //   applications of one layer in a step share one launch, one set of slabs and one reduce
     float* ws;           // [splits][9*C][K] f32 slabs
     int N, H, W, C, K, reflect;
-    int tiles, tiles_per_split;
+    int tiles, tiles_per_split;   // tiles counts both pairs
 };
 
 // 16-byte chunk XOR key of halo row `row` (128-byte rows, two per 256-byte bank line): a transposing read touches rows
@@ -2340,7 +2342,12 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
     const int tilesW = a.W / W9_TW, tilesH = a.H >> 1;
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
-    auto stage_tile = [&](int stg, int t) {
+    const int tiles1 = a.x2 ? a.tiles >> 1 : a.tiles;    // tiles of the first (x, dy) pair
+    auto stage_tile = [&](int stg, int tt) {
+        const bool second = tt >= tiles1;
+        const int t = second ? tt - tiles1 : tt;
+        const char* xs = second ? a.x2 : a.x;
+        const char* dys = second ? a.dy2 : a.dy;
         const int tw = t % tilesW, rest = t / tilesW;
         const int th = rest % tilesH, n = rest / tilesH;
         const int h0 = th * 2, w0 = tw * W9_TW;
@@ -2353,7 +2360,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
             const int px = d * 4 + (lane >> 4), pos = lane & 15;
             const int key = wg2_key<bf16>(px) & 15;
             const int trow = px >> 6, tcol = px & 63;
-            const char* src = a.dy + ((((size_t)n * a.H + h0 + trow) * a.W + w0 + tcol) * a.K + n0) * 2 + ((pos ^ key) << 4);
+            const char* src = dys + ((((size_t)n * a.H + h0 + trow) * a.W + w0 + tcol) * a.K + n0) * 2 + ((pos ^ key) << 4);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(sD + d * 1024), 16, 0, 0);
         }
@@ -2371,7 +2378,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
                 hi = hi < 0 ? -hi : (hi >= a.H ? 2 * (a.H - 1) - hi : hi);
                 wi = wi < 0 ? -wi : (wi >= a.W ? 2 * (a.W - 1) - wi : wi);
             } else ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            const char* src = ok ? a.x + ((((size_t)n * a.H + hi) * a.W + wi) * a.C + c0) * 2 + ((pos ^ key) << 4) : zero;
+            const char* src = ok ? xs + ((((size_t)n * a.H + hi) * a.W + wi) * a.C + c0) * 2 + ((pos ^ key) << 4) : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(sX + (k * W9_PITCH + cg * 8) * 128), 16, 0, 0);
         }
@@ -2469,14 +2476,15 @@ static bool w9_ok(const sgg_conv_desc* d) {
     return d->W % W9_TW == 0 && d->H % 2 == 0 && d->C % 64 == 0 && d->K % 128 == 0;
 }
 static int w9_tiles(const sgg_conv_desc* d) { return d->N * (d->H / 2) * (d->W / W9_TW); }
-static int w9_tiles_per_split(const sgg_conv_desc* d) {
+// the split count depends on the single-pair tile count only, so a paired launch needs the same workspace
+static int w9_splits(const sgg_conv_desc* d) {
     const int otiles = (d->C / 64) * (d->K / 128), T = w9_tiles(d);
     int sp = otiles >= 256 ? 1 : 256 / otiles;
     if (sp > T) sp = T;
     if (sp > 64) sp = 64;
-    return (T + sp - 1) / sp;
+    const int tps = (T + sp - 1) / sp;
+    return (T + tps - 1) / tps;
 }
-static int w9_splits(const sgg_conv_desc* d) { const int tps = w9_tiles_per_split(d); return (w9_tiles(d) + tps - 1) / tps; }
 
 template <typename T, int BMW, int BNW, int WGM>
 static int launch_wgrad_cfg(WgradArgs& a, int splits, hipStream_t s) {
@@ -2518,6 +2526,27 @@ static int wgrad_splits(const sgg_conv_desc* d) {
     return (int)sp;
 }
 
+static int run_w9(const sgg_conv_desc* d, const void* x, const void* dy, const void* x2, const void* dy2, float* dw, int Cr, int Kr,
+                  int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+    const int sp = w9_splits(d);
+    size_t need9 = (size_t)sp * 9 * d->C * d->K * sizeof(float);
+    if (ws_bytes < need9 || !ws) return SGG_EWORKSPACE;
+    W9Args w;
+    w.x = (const char*)x; w.dy = (const char*)dy; w.x2 = (const char*)x2; w.dy2 = (const char*)dy2; w.ws = (float*)ws;
+    w.N = d->N; w.H = d->H; w.W = d->W; w.C = d->C; w.K = d->K; w.reflect = d->pad_mode == SGG_PAD_REFLECT;
+    w.tiles = w9_tiles(d) * (x2 ? 2 : 1);
+    w.tiles_per_split = (w.tiles + sp - 1) / sp;
+    static bool attr9 = false;
+    if (!attr9) { hipFuncSetAttribute((const void*)conv3x3_wgrad_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W9_STAGE); attr9 = true; }
+    hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel, dim3((unsigned)(sp * (d->C / 64) * (d->K / 128))), dim3(512), 2 * W9_STAGE, s, w);
+    int rc9 = sgg_check_launch();
+    if (rc9) return rc9;
+    int64_t total9 = (int64_t)9 * Cr * (d->K / 4);
+    int blocks9 = (int)((total9 + 255) / 256); if (blocks9 > 4096) blocks9 = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks9), dim3(256), 0, s, (const float*)ws, dw, 9, d->C, d->K, Cr, Kr, sp, accumulate);
+    return sgg_check_launch();
+}
+
 template <typename T>
 static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, float* dw, int Cr, int Kr, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
     WgradArgs a;
@@ -2543,24 +2572,7 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
         return sgg_check_launch();
     }
     if constexpr (sizeof(T) == 2) {
-        if (w9_ok(d)) {                                   // 3x3 s1: x halo resident, all taps per block
-            const int sp = w9_splits(d);
-            size_t need9 = (size_t)sp * 9 * d->C * d->K * sizeof(float);
-            if (ws_bytes < need9 || !ws) return SGG_EWORKSPACE;
-            W9Args w;
-            w.x = (const char*)x; w.dy = (const char*)dy; w.ws = (float*)ws;
-            w.N = d->N; w.H = d->H; w.W = d->W; w.C = d->C; w.K = d->K; w.reflect = d->pad_mode == SGG_PAD_REFLECT;
-            w.tiles = w9_tiles(d); w.tiles_per_split = w9_tiles_per_split(d);
-            static bool attr9 = false;
-            if (!attr9) { hipFuncSetAttribute((const void*)conv3x3_wgrad_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W9_STAGE); attr9 = true; }
-            hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel, dim3((unsigned)(sp * (d->C / 64) * (d->K / 128))), dim3(512), 2 * W9_STAGE, s, w);
-            int rc9 = sgg_check_launch();
-            if (rc9) return rc9;
-            int64_t total9 = (int64_t)9 * Cr * (d->K / 4);
-            int blocks9 = (int)((total9 + 255) / 256); if (blocks9 > 4096) blocks9 = 4096;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks9), dim3(256), 0, s, (const float*)ws, dw, 9, d->C, d->K, Cr, Kr, sp, accumulate);
-            return sgg_check_launch();
-        }
+        if (w9_ok(d)) return run_w9(d, x, dy, nullptr, nullptr, dw, Cr, Kr, accumulate, ws, ws_bytes, s);   // 3x3 s1: x halo resident, all taps per block
     }
     int splits = wgrad_splits(d);
     a.pix_per_split = (int)align_up((size_t)((a.P + splits - 1) / splits), 64);
@@ -2712,6 +2724,18 @@ int sgg_conv2d_bwd_weight(const sgg_conv_desc* d, const void* x, const void* dy,
     if (!desc_ok(d) || !x || !dy || !dw || Cr <= 0 || Kr <= 0 || Cr > d->C || Kr > d->K) return SGG_EINVAL;
     return d->dtype == SGG_BF16 ? run_wgrad<bf16>(d, x, dy, dw, Cr, Kr, accumulate, ws, ws_bytes, (hipStream_t)stream)
                                 : run_wgrad<float>(d, x, dy, dw, Cr, Kr, accumulate, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// Weight gradient of TWO applications of one layer (same shape) in one launch: dw (+)= wgrad(x0, dy0) + wgrad(x1, dy1).
+// Only the shapes of the all-taps 3x3 kernel (SGG_EUNSUPPORTED otherwise: call sgg_conv2d_bwd_weight twice);
+// workspace as for a single call.
+int sgg_conv2d_bwd_weight_pair_supported(const sgg_conv_desc* d) { return desc_ok(d) && w9_ok(d) ? 1 : 0; }
+
+int sgg_conv2d_bwd_weight_pair(const sgg_conv_desc* d, const void* x0, const void* dy0, const void* x1, const void* dy1, float* dw,
+                               int Cr, int Kr, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    if (!desc_ok(d) || !x0 || !dy0 || !x1 || !dy1 || !dw || Cr <= 0 || Kr <= 0 || Cr > d->C || Kr > d->K) return SGG_EINVAL;
+    if (!w9_ok(d)) return SGG_EUNSUPPORTED;
+    return run_w9(d, x0, dy0, x1, dy1, dw, Cr, Kr, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
 
 size_t sgg_deconv2d_fwd_workspace(const sgg_conv_desc* d) {

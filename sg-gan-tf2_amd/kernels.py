@@ -78,7 +78,7 @@ def same_pads(n_in: int, k: int, s: int):
 
 class ConvGeom:
     """Geometry of one Conv2D / Conv2DTranspose call site, resolved to an sgg_conv_desc."""
-    __slots__ = ("desc", "x_shape", "y_shape", "ws_wgrad", "ws_dgrad", "ws_fwd", "dtype", "is_deconv", "stats_chunks")
+    __slots__ = ("desc", "x_shape", "y_shape", "ws_wgrad", "ws_dgrad", "ws_fwd", "dtype", "is_deconv", "stats_chunks", "wgrad_pair")
 
     def __init__(self, desc, x_shape, y_shape, dtype, is_deconv):
         self.desc, self.x_shape, self.y_shape, self.dtype, self.is_deconv = desc, x_shape, y_shape, dtype, is_deconv
@@ -86,6 +86,8 @@ class ConvGeom:
         L = A.lib()
         # pixel chunks of the (sum, sumsq) rows the forward conv can emit for a following instance norm (0: it cannot)
         self.stats_chunks = 0 if is_deconv else int(L.sgg_conv2d_fwd_stats_chunks(C.byref(desc)))
+        # the weight gradients of two applications of the layer can share one launch (cycle step)
+        self.wgrad_pair = (not is_deconv) and bool(L.sgg_conv2d_bwd_weight_pair_supported(C.byref(desc)))
         # workspaces of the two GEMM directions; a deconv runs the conv's data-gradient kernel forwards
         self.ws_fwd = int((L.sgg_deconv2d_fwd_workspace if is_deconv else L.sgg_conv2d_fwd_workspace)(C.byref(desc)))
         self.ws_dgrad = int((L.sgg_deconv2d_bwd_data_workspace if is_deconv else L.sgg_conv2d_bwd_data_workspace)(C.byref(desc)))
@@ -184,6 +186,19 @@ def conv_wgrad(g: ConvGeom, x, dy, dw, accumulate=False):
     if pr: pr.start()
     A.check(A.lib().sgg_conv2d_bwd_weight(C.byref(g.desc), _p(x), _p(dy), _p(dw), dw.shape[2], dw.shape[3], int(accumulate),
                                           _p(ws), ws.numel(), _s()), "conv2d_bwd_weight")
+    if pr: pr.stop()
+
+
+def conv_wgrad_pair(g: ConvGeom, x0, dy0, x1, dy1, dw, accumulate=False):
+    """dw (+)= wgrad(x0, dy0) + wgrad(x1, dy1): two applications of one layer, one launch (needs g.wgrad_pair)."""
+    assert g.wgrad_pair and dw.dtype == torch.float32
+    for x, dy in ((x0, dy0), (x1, dy1)):
+        assert tuple(x.shape) == g.x_shape and tuple(dy.shape) == g.y_shape
+    ws = workspace(g.ws_wgrad, x0.device)
+    pr = _prof("conv2d_bwd_weight_pair", g)
+    if pr: pr.start()
+    A.check(A.lib().sgg_conv2d_bwd_weight_pair(C.byref(g.desc), _p(x0), _p(dy0), _p(x1), _p(dy1), _p(dw), dw.shape[2], dw.shape[3],
+                                               int(accumulate), _p(ws), ws.numel(), _s()), "conv2d_bwd_weight_pair")
     if pr: pr.stop()
 
 

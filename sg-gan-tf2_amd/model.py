@@ -81,6 +81,7 @@ class sggan(object):
         # use_pool is set (upstream SG-GAN behaviour: D sees a history of fakes)
         self.pool = ImagePool(g("max_size", 50), rng=g("pool_rng", None))
         self.use_pool = bool(g("use_pool", False))
+        self.pair_wgrads = bool(g("pair_wgrads", True))   # cycle step: one weight-gradient launch per layer for both applications of a G
         self.batch_d_real_fake = bool(g("batch_d_real_fake", True))   # pool mode: D(real) and D(pooled fakes) as one 2N pass
         self.gen_loss_metric, self.disc_loss_metric, self._metric_n = 0.0, 0.0, 0
 
@@ -230,14 +231,18 @@ class sggan(object):
             DB_real, tDBr = Db.forward(rB, mB)
             d_loss_pass(Db, rB, mB, DB_real, tDBr, pooled_B, pfB if pooled_B else None, smA if pooled_B else None, DB_fake, tDBf, False)
         hDb = self._allreduce(Db)
-        # generator gradients: cycle terms first (they reach the other generator through the fakes)
+        # generator gradients: cycle terms first (they reach the other generator through the fakes).  Each generator is
+        # applied twice, so the weight gradients of its 3x3 layers are paired: deferred here, launched with the second pass
+        Gab.pair_wgrads = Gba.pair_wgrads = self.pair_wgrads
         d_fB = K.add(d_fB, Gba.backward(t4, d_cycA, want_dx=True))
         d_fA = K.add(d_fA, Gab.backward(t2, d_cycB, want_dx=True))
         d_fB = K.add(d_fB, Db.backward(tDBf, gB_g, want_dx=True, param_grads=False))
         d_fA = K.add(d_fA, Da.backward(tDAf, gA_g, want_dx=True, param_grads=False))
         Gba.backward(t3, d_fA)
+        Gba.flush_wgrads(); Gba.pair_wgrads = False
         hGba = self._allreduce(Gba)
         Gab.backward(t1, d_fB)
+        Gab.flush_wgrads(); Gab.pair_wgrads = False
         hGab = self._allreduce(Gab)
 
         scale = 1.0 / self._world

@@ -175,6 +175,14 @@ class _ConvUnit:
         else:                                                       # (kh,kw,out,in)
             self.cout, self.cin = shape[2], shape[3]
         self._packed = (-1, None, None)
+        self._pending = None                                        # deferred weight-gradient operands (pair_wgrads)
+
+    def flush_wgrad(self):
+        """Run a deferred weight gradient whose partner never came."""
+        if self._pending is not None:
+            g, x, dxc = self._pending
+            self._pending = None
+            K.conv_wgrad(g, x, dxc, self.net.P.g(self.name + "_w"), accumulate=True)
 
     def geom(self, x):
         N, H, W, Cp = x.shape
@@ -230,7 +238,21 @@ class _ConvUnit:
             if param_grads:
                 K.bias_grad(dxc, P.g(n + "_b", buf=gbuf), accumulate=True)
         if param_grads:
-            (K.conv_wgrad if self.kind == "conv" else K.deconv_wgrad)(g, x, dxc, P.g(n + "_w", buf=gbuf), accumulate=True)
+            if self.kind == "conv" and g.wgrad_pair and self.net.pair_wgrads and gbuf is None:
+                # the net is applied twice this step: keep the first application's operands and run both weight
+                # gradients as ONE launch when the second arrives (one set of split slabs, one reduce)
+                if self._pending is None:
+                    self._pending = (g, x, dxc)
+                else:
+                    g0, x0, d0 = self._pending
+                    self._pending = None
+                    if g0.x_shape == g.x_shape:
+                        K.conv_wgrad_pair(g, x0, d0, x, dxc, P.g(n + "_w"), accumulate=True)
+                    else:
+                        K.conv_wgrad(g0, x0, d0, P.g(n + "_w"), accumulate=True)
+                        K.conv_wgrad(g, x, dxc, P.g(n + "_w"), accumulate=True)
+            else:
+                (K.conv_wgrad if self.kind == "conv" else K.deconv_wgrad)(g, x, dxc, P.g(n + "_w", buf=gbuf), accumulate=True)
         if not want_dx:
             return None
         if self.kind == "conv":
@@ -252,6 +274,16 @@ class _Net:
             self.P.init_keras(seed)
         self._scratch = None
         self._tv = None
+        # set by a step that applies this net exactly twice (the cycle step): weight gradients of layers that support
+        # it are deferred at the first backward and run with the second as one launch (_ConvUnit.backward)
+        self.pair_wgrads = False
+
+    def conv_units(self):
+        return ()
+
+    def flush_wgrads(self):
+        for u in self.conv_units():
+            u.flush_wgrad()
 
     def scratch_vec(self, n):
         if self._scratch is None or self._scratch.numel() < n:
@@ -294,6 +326,9 @@ class Generator(_Net):
         self.d1 = U("d1", "deconv", stride=2, act=A.ACT_RELU)                      # :254-256
         self.d2 = U("d2", "deconv", stride=2, act=A.ACT_RELU)                      # :258-260
         self.out = U("out", "conv", reflect=3, norm=False, act=A.ACT_TANH)         # :262-265
+
+    def conv_units(self):
+        return [self.c1, self.c2, self.c3] + [u for pair in self.blocks for u in pair] + [self.d1, self.d2, self.out]
 
     def forward(self, x):
         """x: internal (N,H,W,8).  Returns (fake internal (N,H,W,8), tape)."""

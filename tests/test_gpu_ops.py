@@ -139,6 +139,26 @@ def test_conv_fwd_stats_epilogue(sg, shape):
     assert g2.stats_chunks == 0
 
 
+def test_conv_wgrad_pair(sg):
+    """sgg_conv2d_bwd_weight_pair: one launch for two applications of a layer == the two separate weight gradients."""
+    from sggan_amd import kernels as K
+    N, H, W, Ci, Co = 2, 4, 128, 64, 128
+    rng = np.random.default_rng(8)
+    g = K.conv_geom(N, H, W, Ci, Co, 3, 3, 1, "VALID", 1, torch.bfloat16)
+    assert g.wgrad_pair
+    xs = [dev(rng.standard_normal(g.x_shape), torch.bfloat16) for _ in range(2)]
+    dys = [dev(rng.standard_normal(g.y_shape), torch.bfloat16) for _ in range(2)]
+    ref = torch.zeros((3, 3, Ci, Co), device="cuda")
+    K.conv_wgrad(g, xs[0], dys[0], ref, accumulate=True)
+    K.conv_wgrad(g, xs[1], dys[1], ref, accumulate=True)
+    got = torch.full((3, 3, Ci, Co), 1.0, device="cuda")
+    K.conv_wgrad_pair(g, xs[0], dys[0], xs[1], dys[1], got, accumulate=True)
+    err = (got - 1.0 - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-5, err
+    g2 = K.conv_geom(N, 5, 7, Ci, Co, 3, 3, 1, "VALID", 1, torch.bfloat16)
+    assert not g2.wgrad_pair
+
+
 DECONV_CASES = [("d1_like", 16, 8, 6, 5), ("d2_like", 24, 16, 4, 8), ("wide", 128, 64, 5, 7), ("odd_c", 8, 3, 3, 3),
                 ("s2halo_d2_like", 128, 64, 8, 32), ("s2halo_d1_like", 256, 128, 16, 32)]
 

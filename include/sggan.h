@@ -86,6 +86,16 @@ size_t sgg_conv2d_bwd_data_workspace(const sgg_conv_desc* d);
  * residual block (module.py:217) folded into the epilogue. */
 int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w_dgrad, const void* addend, void* dx,
                         void* ws, size_t ws_bytes, void* stream);
+
+/* conv2d data gradient that also emits the first pass of the instance-norm BACKWARD that consumes dx (the norm in front of
+ * this conv in the forward direction, module.py:212-215): partial[N][chunks][Cpad][2] = per pixel chunk (sum g, sum g*xhat),
+ * g = dx * act'(gamma*xhat + beta), xhat = (norm_x - mean) * rstd from norm_stats (as written by sgg_instnorm_fwd).
+ * chunks = sgg_conv2d_bwd_data_stats_chunks(d) (0: unsupported shape; currently the bf16 3x3 stride-1 kernel).
+ * Feed partial to sgg_instnorm_bwd_partial().  ws as for sgg_conv2d_bwd_data. */
+size_t sgg_conv2d_bwd_data_stats_chunks(const sgg_conv_desc* d);
+int sgg_conv2d_bwd_data_stats(const sgg_conv_desc* d, const void* dy, const void* w_dgrad, const void* addend, void* dx,
+                              const void* norm_x, const float* norm_stats, const float* norm_gamma, const float* norm_beta,
+                              int norm_act, float norm_leak, float* partial, void* ws, size_t ws_bytes, void* stream);
 /* bwd_weight: dw_hwio[R][S][C_real][K_real] f32, overwritten (accumulate=0) or added to (accumulate=1: a network
  * applied twice in one step, model.py:186-187).  ws: sgg_conv2d_bwd_weight_workspace() bytes. */
 size_t sgg_conv2d_bwd_weight_workspace(const sgg_conv_desc* d);
@@ -136,6 +146,11 @@ int sgg_instnorm_fwd_partial(const void* x, const float* gamma, const float* bet
 int sgg_instnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats,
                      void* dx, float* dgamma, float* dbeta, int N, int64_t HW, int C, int C_real, int accumulate,
                      int act, float leak, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* same, with the statistics pass replaced by precomputed partial sums partial[N][chunks][C][2] (sgg_conv2d_bwd_data_stats);
+ * ws >= N*C*4 floats */
+int sgg_instnorm_bwd_partial(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
+                             float* dgamma, float* dbeta, const float* partial, int chunks, int N, int64_t HW, int C, int C_real,
+                             int accumulate, int act, float leak, int dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- lrelu / relu / tanh: tf.keras.layers.LeakyReLU / Activation ---- module.py:213,265,285 (ops.py:36-37) */
 int sgg_act_fwd(const void* x, void* y, int64_t n, int act, float leak, int dtype, void* stream);

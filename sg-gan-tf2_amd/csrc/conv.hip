@@ -32,8 +32,14 @@ struct ConvArgs {
     char* dst;           // FWD: y (N,Ho,Wo,K)  DGRAD: dx (N,H,W,C)
     const char* addend;  // optional tensor added to the result (same layout as dst): the skip-connection gradient
     const char* fold;    // REFLECT DGRAD (v2): pre-folded gather rows of the border pixels [pixel][tap][K], else nullptr
-    float* stats;        // halo 3x3 forward only: per-(image, pixel chunk, channel) (sum, sumsq) of the stored output for the
-                         // instance norm that follows, [N][chunks][K][2] f32; nullptr = not wanted
+    float* stats;        // halo 3x3 kernels only: per-(image, pixel chunk, channel) partial sums for the instance norm next to
+                         // the conv, [N][chunks][DC][2] f32; nullptr = not wanted.  Forward: (sum, sumsq) of the output.
+                         // Data gradient: (sum g, sum g*xhat) of the norm backward that consumes dx, which needs:
+    const char* nx;      //   that norm's input (same shape as dst)
+    const float* nstats; //   its (mean, rstd)[N][DC]
+    const float* ngamma; //   gamma, beta [DC]
+    const float* nbeta;
+    int nact; float nleak;   // and the activation fused behind it
     float* partial;      // split-K (v2): f32 slabs [ksplit][pdst][DC]
     int ksplit;          // 1 = no split
     int ablate;          // timing experiments only (SGG_ABLATE): 1 no in-loop DMA, 2 no LDS reads/MFMAs, 3 = 1 + no barrier,
@@ -671,7 +677,7 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
 //   columns: the two pixels per tile row in columns 1 / W-2 read their gather row per tap from a small LDS patch
 //            (2 x 2 x 9 rows per chunk, from a.fold's first part, which holds the complete mirrored sums for those
 //            pixels) through a per-lane address select in the first / last pixel fragment.
-template <int MODE, bool FOLD, bool STATS = false>
+template <int MODE, bool FOLD, int STATS = 0>        // STATS: 0 none, 1 forward norm sums, 2 backward norm sums
 __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     constexpr int BN = 256, WGM = 2, WGN = 4, WM = 128, WN = 64, MI = 8, NI = 4, BKB = 128, KK = 2;
     constexpr int QA = 4;                              // weight rows per thread per tile (8 waves x 8 rows x 4)
@@ -860,29 +866,33 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     }
 
     if (a.ablate == 6) return;
-    float bv[NI][4];
+    // Epilogue, one 16-channel group at a time.  STATS 1 (forward): per-channel (sum, sumsq) of the STORED output for the
+    // instance norm that follows the conv.  STATS 2 (data gradient): the first pass of the instance-norm BACKWARD that
+    // consumes this gradient, (sum g, sum g*xhat) with g = dx * act'(gamma*xhat + beta) and xhat from that norm's input
+    // a.nx and statistics a.nstats (norm.hip in_partial_kernel<BWD>).  Each wave reduces its 128 pixels x 64 channels
+    // (registers -> 16-lane butterfly, fixed order) and writes one row per channel as pixel chunk (tile, wave row) of the
+    // image, so the norm skips its own statistics pass over the tensor.
+    const size_t prow = ((size_t)img * a.H + h0 + wm) * a.W + w0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int dc = n0 + wn * WN + i * 16 + fq * 4;
+        if (dc >= DC) continue;
+        float bv[4], s1[4], s2[4], mu[4], rs[4], gm[4], bt[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bv[i][e] = (a.bias && dc < DC) ? a.bias[dc + e] : 0.f;
-    }
-    const size_t prow = ((size_t)img * a.H + h0 + wm) * a.W + w0;
-    float s1[NI][4], s2[NI][4];                       // STATS: this lane's share of sum / sum of squares per channel
+        for (int e = 0; e < 4; ++e) {
+            bv[e] = a.bias ? a.bias[dc + e] : 0.f;
+            s1[e] = s2[e] = 0.f;
+            if (STATS == 2) {
+                mu[e] = a.nstats[((size_t)img * DC + dc + e) * 2]; rs[e] = a.nstats[((size_t)img * DC + dc + e) * 2 + 1];
+                gm[e] = a.ngamma[dc + e]; bt[e] = a.nbeta[dc + e];
+            }
+        }
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s1[i][e] = s2[i][e] = 0.f;
-#pragma unroll
-    for (int j = 0; j < MI; ++j) {
-        const size_t dpix = prow + j * 16 + frow;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int dc = n0 + wn * WN + i * 16 + fq * 4;
-            if (dc >= DC) continue;
+        for (int j = 0; j < MI; ++j) {
+            const size_t dpix = prow + j * 16 + frow;
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[i][j][e] + bv[i][e], a.act, a.leak);
+            for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[i][j][e] + bv[e], a.act, a.leak);
             if (a.addend) {
                 const bf16* ad = reinterpret_cast<const bf16*>(a.addend) + dpix * DC + dc;
 #pragma unroll
@@ -890,36 +900,35 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             }
             bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
             *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.dst) + dpix * DC + dc) = pk;
-            if (STATS) {                              // statistics of what was STORED (the values the norm will read)
+            if (STATS == 1) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float vr = (float)pk[e]; s1[i][e] += vr; s2[i][e] += vr * vr; }
+                for (int e = 0; e < 4; ++e) { const float vr = (float)pk[e]; s1[e] += vr; s2[e] += vr * vr; }
+            }
+            if (STATS == 2) {
+                const bf16x4 xq = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(a.nx) + dpix * DC + dc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = ((float)xq[e] - mu[e]) * rs[e];
+                    const float g = (float)pk[e] * act_grad_from_pre(gm[e] * xh + bt[e], a.nact, a.nleak);
+                    s1[e] += g; s2[e] += g * xh;
+                }
             }
         }
-    }
-    if (STATS) {
-        // The instance norm that follows needs per-(image, channel) mean / variance: each wave reduces its 128 pixels x
-        // 64 channels here (registers -> 16-lane butterfly, fixed order) and writes one (sum, sumsq) row per channel as
-        // pixel chunk (tile, wave row) of the image, replacing the norm's own first pass over the tensor.
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
+        if (STATS) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
 #pragma unroll
                 for (int off = 1; off < 16; off <<= 1) {
-                    s1[i][e] += __shfl_xor(s1[i][e], off);
-                    s2[i][e] += __shfl_xor(s2[i][e], off);
+                    s1[e] += __shfl_xor(s1[e], off);
+                    s2[e] += __shfl_xor(s2[e], off);
                 }
             }
-        if (frow == 0) {
-            const int chunks = tilesH * tilesW * 2;
-            const int chunk = (th * tilesW + tw) * 2 + wm;
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int dc = n0 + wn * WN + i * 16 + fq * 4;
-                if (dc >= DC) continue;
+            if (frow == 0) {
+                const int chunks = tilesH * tilesW * 2;
+                const int chunk = (th * tilesW + tw) * 2 + wm;
                 float* o = a.stats + (((size_t)img * chunks + chunk) * DC + dc) * 2;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { o[2 * e] = s1[i][e]; o[2 * e + 1] = s2[i][e]; }
+                for (int e = 0; e < 4; ++e) { o[2 * e] = s1[e]; o[2 * e + 1] = s2[e]; }
             }
         }
     }
@@ -1144,7 +1153,7 @@ static bool halo3_ok(const ConvArgs& a, int mode, bool is_bf16) {
     return mode == MODE_FWD || mode == MODE_DGRAD;
 }
 
-template <int MODE, bool FOLD, bool STATS = false>
+template <int MODE, bool FOLD, int STATS = 0>
 static int launch_halo3(const ConvArgs& a, hipStream_t s) {
     auto kern = conv3x3_halo_gemm_kernel<MODE, FOLD, STATS>;
     constexpr int lds = FOLD ? H3_LDS_FOLD : H3_LDS;
@@ -2119,7 +2128,7 @@ static bool desc_ok(const sgg_conv_desc* d) {
 
 static ConvArgs make_args(const sgg_conv_desc* d, const void* src, const void* w, const float* bias, void* dst, int act, float leak) {
     ConvArgs a;
-    a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst; a.addend = nullptr; a.fold = nullptr; a.stats = nullptr; a.partial = nullptr; a.ksplit = 1; a.pdst = 0;
+    a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst; a.addend = nullptr; a.fold = nullptr; a.stats = nullptr; a.nx = nullptr; a.nstats = nullptr; a.ngamma = nullptr; a.nbeta = nullptr; a.nact = 0; a.nleak = 0.f; a.partial = nullptr; a.ksplit = 1; a.pdst = 0;
     { static int ab = -1; if (ab < 0) { const char* e = getenv("SGG_ABLATE"); ab = e ? atoi(e) : 0; } a.ablate = ab; }
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S; a.stride = d->stride;
     a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.reflect = d->pad_mode == SGG_PAD_REFLECT;
@@ -2212,8 +2221,11 @@ static int launch_gemm(const ConvArgs& a, hipStream_t s) {
     }
     if constexpr (MODE != MODE_BORDER && sizeof(T) == 2) {
         if (halo3_ok(a, MODE, true)) {
-            if constexpr (MODE == MODE_DGRAD) { if (a.reflect) return launch_halo3<MODE_DGRAD, true>(a, s); }
-            if constexpr (MODE == MODE_FWD) { if (a.stats) return launch_halo3<MODE_FWD, false, true>(a, s); }
+            if constexpr (MODE == MODE_DGRAD) {
+                if (a.reflect) return a.stats ? launch_halo3<MODE_DGRAD, true, 2>(a, s) : launch_halo3<MODE_DGRAD, true>(a, s);
+                if (a.stats) return launch_halo3<MODE_DGRAD, false, 2>(a, s);
+            }
+            if constexpr (MODE == MODE_FWD) { if (a.stats) return launch_halo3<MODE_FWD, false, 1>(a, s); }
             return launch_halo3<MODE, false>(a, s);
         }
     }
@@ -2673,10 +2685,17 @@ size_t sgg_conv2d_bwd_data_workspace(const sgg_conv_desc* d) {
     return fold_bytes(d) + plan_gemm(d, MODE_DGRAD).ws_bytes;
 }
 
-int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w, const void* addend, void* dx, void* ws, size_t ws_bytes, void* stream) {
+struct NormBwdStats { const void* nx; const float* nstats; const float* ngamma; const float* nbeta; int nact; float nleak; float* partial; };
+
+static int conv2d_bwd_data_impl(const sgg_conv_desc* d, const void* dy, const void* w, const void* addend, void* dx, const NormBwdStats* nb,
+                                void* ws, size_t ws_bytes, void* stream) {
     if (!desc_ok(d) || !dy || !w || !dx) return SGG_EINVAL;
     ConvArgs a = make_args(d, dy, w, nullptr, dx, SGG_ACT_NONE, 0.f);
     a.addend = (const char*)addend;
+    if (nb) {
+        a.stats = nb->partial; a.nx = (const char*)nb->nx; a.nstats = nb->nstats; a.ngamma = nb->ngamma; a.nbeta = nb->nbeta;
+        a.nact = nb->nact; a.nleak = nb->nleak;
+    }
     if (!addend && halo_narrow_in_ok(d, d->K, d->C)) {  // data-gradient of a narrow-OUTPUT conv (the head): dy has 8 channels
         int rc0 = d->dtype == SGG_BF16 ? launch_halo_narrow_in<bf16>(d, a, 1, (hipStream_t)stream) : launch_halo_narrow_in<float>(d, a, 1, (hipStream_t)stream);
         if (rc0 || !a.reflect) return rc0;
@@ -2713,6 +2732,28 @@ int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w, c
     if (rc || !a.reflect || use_glds()) return rc;
     // v1 REFLECT: a second, small launch adds the mirrored (MirrorPadGrad) terms to the border pixels
     return d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_BORDER>(a, (hipStream_t)stream) : launch_gemm<float, MODE_BORDER>(a, (hipStream_t)stream);
+}
+
+int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w, const void* addend, void* dx, void* ws, size_t ws_bytes, void* stream) {
+    return conv2d_bwd_data_impl(d, dy, w, addend, dx, nullptr, ws, ws_bytes, stream);
+}
+
+// Pixel chunks per image of the instance-norm-backward partial sums sgg_conv2d_bwd_data_stats() emits; 0 = unsupported shape
+size_t sgg_conv2d_bwd_data_stats_chunks(const sgg_conv_desc* d) {
+    if (!desc_ok(d) || d->dtype != SGG_BF16) return 0;
+    ConvArgs a = make_args(d, nullptr, nullptr, nullptr, nullptr, SGG_ACT_NONE, 0.f);
+    if (plan_gemm(d, MODE_DGRAD).ksplit > 1 || !halo3_ok(a, MODE_DGRAD, true)) return 0;
+    return (size_t)(d->H / 2) * (d->W / H3_TW) * 2;
+}
+
+int sgg_conv2d_bwd_data_stats(const sgg_conv_desc* d, const void* dy, const void* w, const void* addend, void* dx,
+                              const void* norm_x, const float* norm_stats, const float* norm_gamma, const float* norm_beta,
+                              int norm_act, float norm_leak, float* partial, void* ws, size_t ws_bytes, void* stream) {
+    if (!norm_x || !norm_stats || !norm_gamma || !norm_beta || !partial) return SGG_EINVAL;
+    if (norm_act == SGG_ACT_TANH) return SGG_EUNSUPPORTED;
+    if (sgg_conv2d_bwd_data_stats_chunks(d) == 0) return SGG_EUNSUPPORTED;
+    NormBwdStats nb{norm_x, norm_stats, norm_gamma, norm_beta, norm_act, norm_leak, partial};
+    return conv2d_bwd_data_impl(d, dy, w, addend, dx, &nb, ws, ws_bytes, stream);
 }
 
 size_t sgg_conv2d_bwd_weight_workspace(const sgg_conv_desc* d) {

@@ -408,4 +408,24 @@ int sgg_instnorm_bwd(const void* dy, const void* x, const float* gamma, const fl
     return sgg_check_launch();
 }
 
+int sgg_instnorm_bwd_partial(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
+                             float* dgamma, float* dbeta, const float* partial, int chunks, int N, int64_t HW, int C, int C_real,
+                             int accumulate, int act, float leak, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !gamma || !beta || !stats || !dx || !dgamma || !dbeta || !partial || chunks <= 0 || N <= 0 || HW <= 0 || C <= 0 ||
+        C % SGG_CPAD || C_real <= 0 || C_real > C) return SGG_EINVAL;
+    if (act == SGG_ACT_TANH) return SGG_EUNSUPPORTED;
+    if (dtype != SGG_BF16 && dtype != SGG_F32) return SGG_EINVAL;
+    if (!ws || ws_bytes < (size_t)N * C * 4 * sizeof(float)) return SGG_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* sums = (float*)ws;
+    float* tot = sums + (size_t)N * C * 2;
+    int rpb = in_rows_per_block(N, HW, C, 0);
+    dim3 ga((unsigned)((HW + rpb - 1) / rpb), N);
+    const InParamGrad pg{tot, dgamma, dbeta, N, C_real, accumulate};
+    hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, sums, tot, HW, C, chunks);
+    if (dtype == SGG_BF16) hipLaunchKernelGGL((in_apply_kernel<bf16, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg);
+    else hipLaunchKernelGGL((in_apply_kernel<float, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg);
+    return sgg_check_launch();
+}
+
 }  // extern "C"

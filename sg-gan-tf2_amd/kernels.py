@@ -78,7 +78,7 @@ def same_pads(n_in: int, k: int, s: int):
 
 class ConvGeom:
     """Geometry of one Conv2D / Conv2DTranspose call site, resolved to an sgg_conv_desc."""
-    __slots__ = ("desc", "x_shape", "y_shape", "ws_wgrad", "ws_dgrad", "ws_fwd", "dtype", "is_deconv", "stats_chunks", "wgrad_pair")
+    __slots__ = ("desc", "x_shape", "y_shape", "ws_wgrad", "ws_dgrad", "ws_fwd", "dtype", "is_deconv", "stats_chunks", "wgrad_pair", "bwd_stats_chunks")
 
     def __init__(self, desc, x_shape, y_shape, dtype, is_deconv):
         self.desc, self.x_shape, self.y_shape, self.dtype, self.is_deconv = desc, x_shape, y_shape, dtype, is_deconv
@@ -88,6 +88,8 @@ class ConvGeom:
         self.stats_chunks = 0 if is_deconv else int(L.sgg_conv2d_fwd_stats_chunks(C.byref(desc)))
         # the weight gradients of two applications of the layer can share one launch (cycle step)
         self.wgrad_pair = (not is_deconv) and bool(L.sgg_conv2d_bwd_weight_pair_supported(C.byref(desc)))
+        # chunks of the norm-backward partial sums the data gradient can emit for the norm that consumes dx (0: it cannot)
+        self.bwd_stats_chunks = 0 if is_deconv else int(L.sgg_conv2d_bwd_data_stats_chunks(C.byref(desc)))
         # workspaces of the two GEMM directions; a deconv runs the conv's data-gradient kernel forwards
         self.ws_fwd = int((L.sgg_deconv2d_fwd_workspace if is_deconv else L.sgg_conv2d_fwd_workspace)(C.byref(desc)))
         self.ws_dgrad = int((L.sgg_deconv2d_bwd_data_workspace if is_deconv else L.sgg_conv2d_bwd_data_workspace)(C.byref(desc)))
@@ -176,6 +178,23 @@ def conv_dgrad(g: ConvGeom, dy, w_dgrad, addend=None):
     A.check(A.lib().sgg_conv2d_bwd_data(C.byref(g.desc), _p(dy), _p(w_dgrad), _p(addend), _p(dx), _p(ws), g.ws_dgrad, _s()), "conv2d_bwd_data")
     if pr: pr.stop()
     return dx
+
+
+def conv_dgrad_stats(g: ConvGeom, dy, w_dgrad, addend, norm_x, norm_stats, norm_gamma, norm_beta, norm_act=A.ACT_NONE, norm_leak=0.0):
+    """conv_dgrad + the first pass of the instance-norm backward that consumes dx (the norm whose input is norm_x)."""
+    assert tuple(dy.shape) == g.y_shape and not g.is_deconv and g.bwd_stats_chunks > 0
+    assert tuple(norm_x.shape) == g.x_shape and norm_x.dtype == dy.dtype
+    assert addend is None or (tuple(addend.shape) == g.x_shape and addend.dtype == dy.dtype)
+    dx = torch.empty(g.x_shape, dtype=dy.dtype, device=dy.device)
+    partial = torch.empty((g.x_shape[0], g.bwd_stats_chunks, g.x_shape[3], 2), dtype=torch.float32, device=dy.device)
+    pr = _prof("conv2d_bwd_data", g)
+    if pr: pr.start()
+    ws = workspace(g.ws_dgrad, dy.device) if g.ws_dgrad else None
+    A.check(A.lib().sgg_conv2d_bwd_data_stats(C.byref(g.desc), _p(dy), _p(w_dgrad), _p(addend), _p(dx), _p(norm_x), _p(norm_stats),
+                                              _p(norm_gamma), _p(norm_beta), norm_act, norm_leak, _p(partial), _p(ws), g.ws_dgrad, _s()),
+            "conv2d_bwd_data_stats")
+    if pr: pr.stop()
+    return dx, partial
 
 
 def conv_wgrad(g: ConvGeom, x, dy, dw, accumulate=False):
@@ -270,6 +289,18 @@ def instnorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, accumulate=False, act
     ws = workspace(int(A.lib().sgg_instnorm_workspace(N, H * W, Cp)), x.device)
     A.check(A.lib().sgg_instnorm_bwd(_p(dy), _p(x), _p(gamma), _p(beta), _p(stats), _p(dx), _p(dgamma), _p(dbeta), N, H * W, Cp,
                                      dgamma.numel(), int(accumulate), act, leak, dt(x), _p(ws), ws.numel(), _s()), "instnorm_bwd")
+    return dx
+
+
+def instnorm_bwd_partial(dy, x, partial, gamma, beta, stats, dgamma, dbeta, accumulate=False, act=A.ACT_NONE, leak=0.0):
+    """instance-norm backward whose statistics pass was done by the conv data gradient that produced dy."""
+    N, H, W, Cp = x.shape
+    assert partial.shape[0] == N and partial.shape[2] == Cp
+    dx = torch.empty_like(x)
+    ws = workspace(N * Cp * 16, x.device)
+    A.check(A.lib().sgg_instnorm_bwd_partial(_p(dy), _p(x), _p(gamma), _p(beta), _p(stats), _p(dx), _p(dgamma), _p(dbeta), _p(partial),
+                                             partial.shape[1], N, H * W, Cp, dgamma.numel(), int(accumulate), act, leak, dt(x),
+                                             _p(ws), ws.numel(), _s()), "instnorm_bwd_partial")
     return dx
 
 

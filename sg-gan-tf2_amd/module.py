@@ -157,6 +157,10 @@ def discriminator_param_specs(df_dim=64, in_c=3, segment_class=34):
 
 # ----------------------------------------------------------------------------- layer engine
 FUSE_CONV_IN_STATS = os.environ.get("SGG_FUSE_IN_STATS", "1") != "0"     # A/B switch for the conv -> norm statistics fusion
+# ... and for its backward counterpart (data-gradient epilogue -> norm-backward sums).  OFF by default: measured at the
+# bench shape the epilogue costs +27 us per data gradient (32 scattered 8-byte reads of the norm input per lane at the
+# end of the kernel) against 18 us for the statistics pass it replaces.  Kept (and parity-tested) as an opt-in.
+FUSE_CONV_IN_BWD = os.environ.get("SGG_FUSE_IN_BWD", "0") != "0"
 
 
 class _ConvUnit:
@@ -222,7 +226,10 @@ class _ConvUnit:
         y, stats = K.instnorm_fwd(xc, P.p(n + "_g"), P.p(n + "_beta"), residual, self.net.eps, self.act, self.leak)
         return y, (g, x, xc, stats)
 
-    def backward(self, rec, dy, want_dx=True, param_grads=True, gbuf=None, addend=None):
+    def backward(self, rec, dy, want_dx=True, param_grads=True, gbuf=None, addend=None, dy_partial=None, next_norm=None):
+        """dy_partial: the norm-backward partial sums of THIS unit's norm, already computed by the data gradient that
+        produced dy.  next_norm = (unit, rec) of the layer that will consume the returned dx: if its norm's first pass can
+        be done in this unit's data-gradient epilogue the call returns (dx, partial) instead of dx."""
         P, n = self.net.P, self.name
         g, x, xc, stats = rec
         wf, wd = self.packed(x.dtype)
@@ -231,7 +238,10 @@ class _ConvUnit:
                 dg, db = P.g(n + "_g", buf=gbuf), P.g(n + "_beta", buf=gbuf)
             else:   # gradients w.r.t. gamma/beta not wanted: send them to scratch
                 dg = db = self.net.scratch_vec(K.cpad(self.cout))
-            dxc = K.instnorm_bwd(dy, xc, P.p(n + "_g"), P.p(n + "_beta"), stats, dg, db, param_grads, self.act, self.leak)
+            if dy_partial is not None:
+                dxc = K.instnorm_bwd_partial(dy, xc, dy_partial, P.p(n + "_g"), P.p(n + "_beta"), stats, dg, db, param_grads, self.act, self.leak)
+            else:
+                dxc = K.instnorm_bwd(dy, xc, P.p(n + "_g"), P.p(n + "_beta"), stats, dg, db, param_grads, self.act, self.leak)
             # the conv bias feeds an InstanceNorm: its gradient is identically 0 -> left at 0
         else:
             dxc = K.act_bwd(dy, xc, self.act, self.leak) if self.act != A.ACT_NONE else dy
@@ -256,9 +266,17 @@ class _ConvUnit:
         if not want_dx:
             return None
         if self.kind == "conv":
+            if next_norm is not None:
+                nu, nrec = next_norm
+                if FUSE_CONV_IN_STATS and FUSE_CONV_IN_BWD and g.bwd_stats_chunks and nu.norm and tuple(nrec[2].shape) == g.x_shape:
+                    NP = nu.net.P
+                    return K.conv_dgrad_stats(g, dxc, wd, addend, nrec[2], nrec[3], NP.p(nu.name + "_g"), NP.p(nu.name + "_beta"),
+                                              nu.act, nu.leak)
+                return K.conv_dgrad(g, dxc, wd, addend), None
             return K.conv_dgrad(g, dxc, wd, addend)
         dx = K.deconv_dgrad(g, dxc, wf)
-        return dx if addend is None else K.add(dx, addend)
+        dx = dx if addend is None else K.add(dx, addend)
+        return (dx, None) if next_norm is not None else dx
 
 
 class _Net:
@@ -351,10 +369,15 @@ class Generator(_Net):
         d = dy
         for u, r in zip((self.out, self.d2, self.d1), (tape[5 + nb], tape[4 + nb], tape[3 + nb])):
             d = u.backward(r, d, True, param_grads, gbuf)
-        for (ua, ub), (ra, rb) in zip(reversed(self.blocks), reversed(tape[3:3 + nb])):
-            t = ub.backward(rb, d, True, param_grads, gbuf)
-            d = ua.backward(ra, t, True, param_grads, gbuf, addend=d)   # + gradient of the skip connection (fused)
-        d = self.c3.backward(tape[2], d, True, param_grads, gbuf)
+        # residual blocks: each data gradient also makes the first pass of the norm backward that consumes it (the
+        # norm of the conv before it in forward order), so that norm skips its statistics pass over the tensor
+        part = None
+        blocks, recs = list(reversed(self.blocks)), list(reversed(tape[3:3 + nb]))
+        for k, ((ua, ub), (ra, rb)) in enumerate(zip(blocks, recs)):
+            t, pa = ub.backward(rb, d, True, param_grads, gbuf, dy_partial=part, next_norm=(ua, ra))
+            nxt = (blocks[k + 1][1], recs[k + 1][1]) if k + 1 < nb else (self.c3, tape[2])
+            d, part = ua.backward(ra, t, True, param_grads, gbuf, addend=d, dy_partial=pa, next_norm=nxt)   # + skip gradient (fused)
+        d = self.c3.backward(tape[2], d, True, param_grads, gbuf, dy_partial=part)
         d = self.c2.backward(tape[1], d, True, param_grads, gbuf)
         return self.c1.backward(tape[0], d, want_dx, param_grads, gbuf)
 

@@ -139,6 +139,38 @@ def test_conv_fwd_stats_epilogue(sg, shape):
     assert g2.stats_chunks == 0
 
 
+@pytest.mark.parametrize("pad,act", [("REFLECT-1", "relu"), ("SAME", None)], ids=["reflect_relu", "zero_none"])
+def test_conv_dgrad_norm_bwd_epilogue(sg, pad, act):
+    """conv data gradient + instance-norm-backward partial sums in its epilogue (sgg_conv2d_bwd_data_stats): dx is
+    bit-identical to the plain data gradient and the norm backward fed with the partials matches the norm backward
+    that makes its own statistics pass (dx, dgamma, dbeta)."""
+    from sggan_amd import kernels as K, _abi as A
+    N, H, W, Ci, Co = 2, 4, 128, 128, 192
+    rng = np.random.default_rng(21)
+    padding, refl = ("VALID", 1) if pad.startswith("REFLECT") else (pad, 0)
+    g = K.conv_geom(N, H, W, Ci, Co, 3, 3, 1, padding, refl, torch.bfloat16)
+    assert g.bwd_stats_chunks == (H // 2) * (W // 128) * 2
+    w = dev(rng.standard_normal((3, 3, Ci, Co)) / np.sqrt(9 * Ci))
+    _, wd = K.pack_weights(w, Ci, Co, torch.bfloat16)
+    dy = dev(rng.standard_normal(g.y_shape), torch.bfloat16)
+    addend = dev(rng.standard_normal(g.x_shape), torch.bfloat16)
+    # the norm in front of the conv: its input nx, statistics, affine parameters
+    nx = dev(rng.standard_normal(g.x_shape) * 1.3 + 0.2, torch.bfloat16)
+    gam, bet = dev(1 + 0.2 * rng.standard_normal(Ci)), dev(0.2 * rng.standard_normal(Ci))
+    a = {"relu": A.ACT_RELU, None: A.ACT_NONE}[act]
+    _, st = K.instnorm_fwd(nx, gam, bet, None, 1e-3, a)
+    dx0 = K.conv_dgrad(g, dy, wd, addend)
+    dx1, part = K.conv_dgrad_stats(g, dy, wd, addend, nx, st, gam, bet, a, 0.0)
+    assert torch.equal(dx0, dx1)
+    dg0, db0, dg1, db1 = (torch.zeros(Ci, device="cuda") for _ in range(4))
+    r0 = K.instnorm_bwd(dx0, nx, gam, bet, st, dg0, db0, False, a)
+    r1 = K.instnorm_bwd_partial(dx1, nx, part, gam, bet, st, dg1, db1, False, a)
+    sc = r0.float().abs().max().item()
+    assert (r0.float() - r1.float()).abs().max().item() < 2e-2 * sc
+    assert (dg0 - dg1).abs().max().item() < 1e-3 * max(1.0, dg0.abs().max().item())
+    assert (db0 - db1).abs().max().item() < 1e-3 * max(1.0, db0.abs().max().item())
+
+
 def test_conv_wgrad_pair(sg):
     """sgg_conv2d_bwd_weight_pair: one launch for two applications of a layer == the two separate weight gradients."""
     from sggan_amd import kernels as K

@@ -202,6 +202,56 @@ def test_bench_size_bf16_step_runs_and_is_sane(sg):
     assert yf.mean((1, 2)).abs().max() < 2e-2 and (yf.var((1, 2), unbiased=False) - want_var).abs().max() < 3e-2
 
 
+def test_fused_paths_match_unfused_at_bench_width(sg):
+    """The bench shape's fast paths -- norm statistics from the conv epilogue, norm-backward sums from the data-gradient
+    epilogue (opt-in), paired weight gradients -- against the same step with all of them off: same kernels otherwise, so
+    losses and every parameter gradient agree to f32-summation-order noise.  (256x512 is the smallest input whose
+    residual maps, 64x128, take the halo-resident 3x3 kernels.)"""
+    import sggan_amd.module as M
+
+    from sggan_amd import kernels as K
+    calls = {"fwd": 0, "bwd": 0, "pair": 0}
+    orig = (K.conv_fwd_stats, K.conv_dgrad_stats, K.conv_wgrad_pair)
+
+    def counted(name, f):
+        def w(*a, **k):
+            calls[name] += 1
+            return f(*a, **k)
+        return w
+
+    def grads(fuse_fwd, fuse_bwd, pair):
+        old = (M.FUSE_CONV_IN_STATS, M.FUSE_CONV_IN_BWD)
+        M.FUSE_CONV_IN_STATS, M.FUSE_CONV_IN_BWD = fuse_fwd, fuse_bwd
+        K.conv_fwd_stats, K.conv_dgrad_stats, K.conv_wgrad_pair = (counted(n, f) for n, f in zip(("fwd", "bwd", "pair"), orig))
+        for k in calls:
+            calls[k] = 0
+        try:
+            m = sg.sggan(sg.default_args(dtype="bf16", cycle=True, n_blocks=2, pair_wgrads=pair))
+            a = _rand_inputs(1, 256, 512, m.discriminator, 5)
+            b = _rand_inputs(1, 256, 512, m.discriminator, 6)
+            m.real_A, m.seg_A, m.mask_A = a
+            m.real_B, m.seg_B, m.mask_B = b
+            m.train_step()
+            gl, dl = m.losses()
+            # 2 generators x 2 applications x 2 blocks x 2 convs = 16 res convs forward; every one of them backward
+            assert calls["fwd"] == (16 if fuse_fwd else 0) and calls["bwd"] == (16 if fuse_bwd else 0)
+            assert calls["pair"] == (8 if pair else 0)
+            return gl, dl, [n.P.grad.clone() for n in m.networks()]
+        finally:
+            M.FUSE_CONV_IN_STATS, M.FUSE_CONV_IN_BWD = old
+            K.conv_fwd_stats, K.conv_dgrad_stats, K.conv_wgrad_pair = orig
+
+    ref = grads(False, False, False)
+    # (pairing only changes the f32 summation order of dW; the statistics fusions move mean / rstd by ~1e-7 relative,
+    # which flips a few bf16 roundings that the 2 x 29-layer bf16 backward chain then amplifies -- DESIGN.md section 6)
+    for cfg, thr in (((False, False, True), 0.9999), ((True, False, True), 0.98), ((True, True, True), 0.98)):
+        got = grads(*cfg)
+        assert abs(got[0] - ref[0]) < 2e-3 * abs(ref[0]) and abs(got[1] - ref[1]) < 2e-3 * abs(ref[1]), (cfg, got[:2], ref[:2])
+        coss = [torch.nn.functional.cosine_similarity(gg.flatten(), gr.flatten(), dim=0).item() for gg, gr in zip(got[2], ref[2])]
+        print("fused-vs-unfused gradient cosines", cfg, [round(c, 5) for c in coss])
+        assert min(coss) > thr, (cfg, coss)
+
+
 def test_cycle_step_small_f32_matches_oracle(sg):
     """2G+2D cycle-mode step (deviation D5) vs the oracle's cycle_step on reduced networks, LSGAN and SCE criteria."""
     rng = np.random.default_rng(23)

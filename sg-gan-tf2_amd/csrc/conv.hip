@@ -2244,12 +2244,9 @@ static int launch_gemm(const ConvArgs& a, hipStream_t s) {
             if (DC >= 128 && Mmax * ((DC + 127) / 128) >= 256 * 160)
                 return deep ? launch_glds_cfg<T, MODE, 256, 128, 4, 8, 64, 4>(a, Mmax, DC, classes, s)
                             : launch_glds_cfg<T, MODE, 256, 128, 4, 8, 128, 2>(a, Mmax, DC, classes, s);
-            if (DC >= 128) {
-                static int w8 = -1;
-                if (w8 < 0) { const char* e = getenv("SGG_128_W8"); w8 = e ? atoi(e) : 0; }
-                if (w8) return launch_glds_cfg<T, MODE, 128, 128, 2, 8>(a, Mmax, DC, classes, s);
-                return launch_glds_cfg<T, MODE, 128, 128, 2, 4>(a, Mmax, DC, classes, s);
-            }
+            // 128x128 with 8 waves (2 per SIMD, two blocks per CU): the 4-wave variant ran at one wave per SIMD with
+            // nothing to cover its LDS latencies (D.h3 data gradient 86 -> 60 us, D.h2 forward 36 -> 23 us)
+            if (DC >= 128) return launch_glds_cfg<T, MODE, 128, 128, 2, 8>(a, Mmax, DC, classes, s);
             if (DC > 16) return launch_glds_cfg<T, MODE, 128, 64, 4, 4>(a, Mmax, DC, classes, s);
             return launch_glds_cfg<T, MODE, 256, 16, 4, 4>(a, Mmax, DC, classes, s);
         }

@@ -27,8 +27,8 @@ MUST_NOT_SPILL = [
     "conv_gemm_glds_kernelIDF16bLi1ELi256ELi256ELi2ELi8ELi128ELi2E",
     "conv_gemm_glds_kernelIDF16bLi0ELi256ELi128ELi4ELi8ELi128ELi2E",
 ]
-# 4-wave configuration: one wave per SIMD by design (accumulators in AGPRs); only spills are checked
-NO_SPILL_ONLY = ["conv_gemm_glds_kernelIDF16bLi0ELi128ELi128ELi2ELi4ELi128ELi2E"]
+# small-tile configurations: only spills are checked
+NO_SPILL_ONLY = ["conv_gemm_glds_kernelIDF16bLi0ELi128ELi128ELi2ELi8ELi128ELi2E", "conv_gemm_glds_kernelIDF16bLi1ELi128ELi128ELi2ELi8ELi128ELi2E"]
 
 
 def test_gemm_kernels_do_not_spill(tmp_path):

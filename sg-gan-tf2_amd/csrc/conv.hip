@@ -873,6 +873,67 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     // (registers -> 16-lane butterfly, fixed order) and writes one row per channel as pixel chunk (tile, wave row) of the
     // image, so the norm skips its own statistics pass over the tensor.
     const size_t prow = ((size_t)img * a.H + h0 + wm) * a.W + w0;
+    if constexpr (STATS != 2) {
+        // pixel-major store order: the four 16-channel groups of a pixel go out back to back, so the 128 bytes a wave
+        // writes per pixel merge into whole lines in L2 (channel-group-major order cost +47 MB of HBM fetches per launch:
+        // partially written lines are read back)
+        float bv[NI][4], s1[NI][4], s2[NI][4];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int dc = n0 + wn * WN + i * 16 + fq * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bv[i][e] = (a.bias && dc < DC) ? a.bias[dc + e] : 0.f; s1[i][e] = s2[i][e] = 0.f; }
+        }
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+            const size_t dpix = prow + j * 16 + frow;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int dc = n0 + wn * WN + i * 16 + fq * 4;
+                if (dc >= DC) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[i][j][e] + bv[i][e], a.act, a.leak);
+                if (a.addend) {
+                    const bf16* ad = reinterpret_cast<const bf16*>(a.addend) + dpix * DC + dc;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)ad[e];
+                }
+                bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.dst) + dpix * DC + dc) = pk;
+                if (STATS == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float vr = (float)pk[e]; s1[i][e] += vr; s2[i][e] += vr * vr; }
+                }
+            }
+        }
+        if (STATS == 1) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int off = 1; off < 16; off <<= 1) {
+                        s1[i][e] += __shfl_xor(s1[i][e], off);
+                        s2[i][e] += __shfl_xor(s2[i][e], off);
+                    }
+                }
+            if (frow == 0) {
+                const int chunks = tilesH * tilesW * 2;
+                const int chunk = (th * tilesW + tw) * 2 + wm;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int dc = n0 + wn * WN + i * 16 + fq * 4;
+                    if (dc >= DC) continue;
+                    float* o = a.stats + (((size_t)img * chunks + chunk) * DC + dc) * 2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[2 * e] = s1[i][e]; o[2 * e + 1] = s2[i][e]; }
+                }
+            }
+        }
+        return;
+    }
+    // STATS 2 (opt-in): one 16-channel group at a time, to keep that group's norm constants in registers
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int dc = n0 + wn * WN + i * 16 + fq * 4;

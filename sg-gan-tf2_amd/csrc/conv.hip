@@ -348,6 +348,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 // what the memory side delivers (PMC: the 128x128 variant was bound there at ~9 TB/s of L2 reads, 93 % hits).
 // -------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[4] = {0u, 0u, 0u, 0u};
+// debug aid (SGG_ABLATE=9): shader-clock and wall-clock timestamps of one block of the halo GEMM, read by sgg_debug_clocks()
+__device__ unsigned long long g_dbg_clk[4];
 
 template <typename T, int MODE, int BM, int BN, int WGM, int NW, int BKB, int NS>
 __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
@@ -708,6 +710,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     const int th = mt % tilesH;
     const int img = mt / tilesH;
     const int h0 = th * 2, w0 = tw * H3_TW;
+    const bool dbg_clk = a.ablate == 9 && lid == 0 && tid == 0;
+    const int abl = a.ablate == 9 ? 0 : a.ablate;    // 9 = full kernel + clock stamps
+    if (dbg_clk) { g_dbg_clk[0] = clock64(); g_dbg_clk[1] = wall_clock64(); }
 
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
@@ -795,11 +800,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    const int ntiles = a.ablate >= 5 ? 0 : nchunk * 9;
+    const int ntiles = abl >= 5 ? 0 : nchunk * 9;
     int chunk = 0, tap = 0;                           // of the tile being multiplied
     for (int t = 0; t < ntiles; ++t) {
         // refill: next weight tile, and the halo rows whose slots are free (see header)
-        if (a.ablate == 0 || a.ablate == 2) {
+        if (abl == 0 || abl == 2) {
             int ntap = tap + 1, nchk = chunk;
             if (ntap == 9) { ntap = 0; ++nchk; }
             if (t + 1 < ntiles) load_w((t + 1) & 1, nchk, MODE == MODE_FWD ? ntap : 8 - ntap);
@@ -832,7 +837,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             }
             return ld16(p);
         };
-        if (a.ablate != 2) {
+        if (abl != 2) {
             constexpr int GJ = 4, GPK = MI / GJ, NG = KK * GPK;
             u32x4 fw[KK][NI];
 #pragma unroll
@@ -861,11 +866,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (a.ablate < 3) __builtin_amdgcn_s_barrier();
+        if (abl < 3) __builtin_amdgcn_s_barrier();
         if (++tap == 9) { tap = 0; ++chunk; }
     }
 
-    if (a.ablate == 6) return;
+    if (dbg_clk) { g_dbg_clk[2] = clock64(); g_dbg_clk[3] = wall_clock64(); }
+    if (abl == 6) return;
     // Epilogue, one 16-channel group at a time.  STATS 1 (forward): per-channel (sum, sumsq) of the STORED output for the
     // instance norm that follows the conv.  STATS 2 (data gradient): the first pass of the instance-norm BACKWARD that
     // consumes this gradient, (sum g, sum g*xhat) with g = dx * act'(gamma*xhat + beta) and xhat from that norm's input
@@ -2682,6 +2688,17 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
 }
 
 extern "C" {
+
+// debug aid (not part of include/sggan.h): timestamps left by the halo GEMM under SGG_ABLATE=9 and the wall-clock rate (kHz)
+int sgg_debug_clocks(unsigned long long* out5) {
+    if (!out5) return SGG_EINVAL;
+    if (hipMemcpyFromSymbol(out5, HIP_SYMBOL(g_dbg_clk), 4 * sizeof(unsigned long long)) != hipSuccess) return SGG_ELAUNCH;
+    int khz = 0, dev = 0;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev);
+    out5[4] = (unsigned long long)khz;
+    return SGG_OK;
+}
 
 // debug aid (not part of include/sggan.h): occupancy the runtime reports for the hot kernels
 int sgg_debug_occupancy(int* out, int cap) {

@@ -157,7 +157,8 @@ class EventProfiler:
         return self._Span(self.records.setdefault(tag, []))
 
     def overhead_ms(self):
-        return float(np.mean([s.elapsed_time(e) for s, e in self.empty])) if self.empty else 0.0
+        # median: an empty pair occasionally straddles a queue hiccup of tens of microseconds
+        return float(np.median([s.elapsed_time(e) for s, e in self.empty])) if self.empty else 0.0
 
     def summary(self):
         """tag -> (mean span minus the event-pair overhead, samples, raw mean span)"""

@@ -64,6 +64,17 @@ const char* sgg_strerror(int status);
 int sgg_pack_conv_weights(const float* w_hwio, int R, int S, int C, int K, int Cpad, int Kpad,
                           int dtype, void* w_fwd, void* w_dgrad, void* stream);
 
+/* The same for every conv layer of a network in one launch (all packed weights go stale together at each optimizer step).
+ * items_dev: DEVICE array of n_items entries; pointers are device pointers, w_fwd / w_dgrad may be NULL;
+ * max_elems = max over items of taps*Cpad*Kpad. */
+typedef struct sgg_pack_item {
+    const float* w;      /* HWIO f32 kernel of the layer */
+    void* w_fwd;
+    void* w_dgrad;
+    int32_t taps, C, K, Cpad, Kpad, reserved;
+} sgg_pack_item;
+int sgg_pack_conv_weights_batch(const sgg_pack_item* items_dev, int n_items, int64_t max_elems, int dtype, void* stream);
+
 /* ---- conv2d: tf.keras.layers.Conv2D (+ tf.pad REFLECT) ---- module.py:210-216,230-232,236,240,262-264,284-311
  * fwd: y = act(conv(x) + bias);  bias may be NULL; bias has Kpad f32 entries.
  * ws: sgg_conv2d_fwd_workspace() bytes (non-zero only for small outputs, which are computed split-K). */

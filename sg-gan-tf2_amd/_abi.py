@@ -24,6 +24,12 @@ class ConvDesc(C.Structure):
                 ("N", "H", "W", "C", "K", "R", "S", "stride", "pad_t", "pad_l", "Ho", "Wo", "pad_mode", "dtype")]
 
 
+class PackItem(C.Structure):
+    """struct sgg_pack_item (include/sggan.h)."""
+    _fields_ = [("w", C.c_void_p), ("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p)] + [(n, C.c_int32) for n in
+                ("taps", "C", "K", "Cpad", "Kpad", "reserved")]
+
+
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 _dp = C.POINTER(ConvDesc)
 
@@ -32,6 +38,7 @@ SIGNATURES = {
     "sgg_version": (_i, []),
     "sgg_strerror": (C.c_char_p, [_i]),
     "sgg_pack_conv_weights": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "sgg_pack_conv_weights_batch": (_i, [_vp, _i, _i64, _i, _vp]),
     "sgg_conv2d_fwd_workspace": (_sz, [_dp]),
     "sgg_conv2d_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _i, _f, _vp, _sz, _vp]),
     "sgg_conv2d_fwd_stats_chunks": (_sz, [_dp]),

@@ -2173,6 +2173,26 @@ __global__ void pack_weights_kernel(const float* w, int taps, int C, int K, int 
     }
 }
 
+// every conv layer of a network in ONE launch (blockIdx.y = layer): after each optimizer step all packed weights are stale,
+// and 16 separate 8-us launches per network were pure launch latency
+template <typename T>
+__global__ void pack_weights_batch_kernel(const sgg_pack_item* items) {
+    const sgg_pack_item it = items[blockIdx.y];
+    const int taps = it.taps, C = it.C, K = it.K, Cpad = it.Cpad, Kpad = it.Kpad;
+    const float* w = it.w;
+    T* wf = (T*)it.w_fwd;
+    T* wd = (T*)it.w_dgrad;
+    int64_t total = (int64_t)taps * Cpad * Kpad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int k = (int)(i % Kpad);
+        int64_t t = i / Kpad;
+        int c = (int)(t % Cpad), tap = (int)(t / Cpad);
+        float v = (c < C && k < K) ? w[((size_t)tap * C + c) * K + k] : 0.f;
+        if (wf) wf[((size_t)k * taps + tap) * Cpad + c] = (T)v;
+        if (wd) wd[((size_t)c * taps + tap) * Kpad + k] = (T)v;
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
@@ -2717,6 +2737,16 @@ int sgg_pack_conv_weights(const float* w, int R, int S, int C, int K, int Cpad, 
     int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
     if (dtype == SGG_BF16) hipLaunchKernelGGL(pack_weights_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, R * S, C, K, Cpad, Kpad, (bf16*)wf, (bf16*)wd);
     else if (dtype == SGG_F32) hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, R * S, C, K, Cpad, Kpad, (float*)wf, (float*)wd);
+    else return SGG_EINVAL;
+    return sgg_check_launch();
+}
+
+int sgg_pack_conv_weights_batch(const sgg_pack_item* items_dev, int n_items, int64_t max_elems, int dtype, void* stream) {
+    if (!items_dev || n_items <= 0 || max_elems <= 0) return SGG_EINVAL;
+    int blocks = (int)((max_elems + 255) / 256); if (blocks > 1024) blocks = 1024;
+    dim3 grid((unsigned)blocks, (unsigned)n_items);
+    if (dtype == SGG_BF16) hipLaunchKernelGGL(pack_weights_batch_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, items_dev);
+    else if (dtype == SGG_F32) hipLaunchKernelGGL(pack_weights_batch_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, items_dev);
     else return SGG_EINVAL;
     return sgg_check_launch();
 }

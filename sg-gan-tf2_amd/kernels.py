@@ -142,6 +142,28 @@ def pack_weights(w_hwio: torch.Tensor, Cp: int, Kp: int, dtype, want_fwd=True, w
     return wf, wd
 
 
+def pack_weights_batch(entries, dtype, device):
+    """entries: [(w_hwio f32 view, Cp, Kp, want_fwd, want_dgrad)].  Allocates the packed buffers once and returns
+    (table, n, max_elems, [(wf, wd)]): the device table of sgg_pack_item for repack_batch()."""
+    items = (A.PackItem * len(entries))()
+    bufs, max_elems = [], 0
+    for it, (w, Cp, Kp, want_fwd, want_dgrad) in zip(items, entries):
+        R, S, Cr, Kr = w.shape
+        assert w.is_contiguous() and w.dtype == torch.float32
+        wf = torch.empty((Kp, R * S * Cp), dtype=dtype, device=device) if want_fwd else None
+        wd = torch.empty((Cp, R * S * Kp), dtype=dtype, device=device) if want_dgrad else None
+        it.w, it.w_fwd, it.w_dgrad = w.data_ptr(), (wf.data_ptr() if wf is not None else None), (wd.data_ptr() if wd is not None else None)
+        it.taps, it.C, it.K, it.Cpad, it.Kpad, it.reserved = R * S, Cr, Kr, Cp, Kp, 0
+        bufs.append((wf, wd))
+        max_elems = max(max_elems, R * S * Cp * Kp)
+    raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(device)
+    return raw, len(entries), max_elems, bufs
+
+
+def repack_batch(table, n, max_elems, dtype):
+    A.check(A.lib().sgg_pack_conv_weights_batch(_p(table), n, max_elems, dt(dtype), _s()), "pack_conv_weights_batch")
+
+
 # ----------------------------------------------------------------------------- conv / deconv
 def conv_fwd(g: ConvGeom, x, w_fwd, bias, act=A.ACT_NONE, leak=0.0):
     assert tuple(x.shape) == g.x_shape and not g.is_deconv, (tuple(x.shape), g.x_shape)

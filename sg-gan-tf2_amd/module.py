@@ -195,16 +195,21 @@ class _ConvUnit:
             return K.conv_geom(N, H, W, Cp, K.cpad(self.cout), self.R, self.S, self.stride, self.padding, self.reflect, x.dtype)
         return K.deconv_geom(N, H, W, Cp, K.cpad(self.cout), self.R, self.S, self.stride, x.dtype)
 
+    def pack_dims(self):
+        """(Cpad, Kpad) of the packed GEMM operands: for a deconv the equivalent conv has C = deconv out, K = deconv in
+        (the stored (kh,kw,out,in) kernel is already that conv's HWIO)."""
+        return (K.cpad(self.cin), K.cpad(self.cout)) if self.kind == "conv" else (K.cpad(self.cout), K.cpad(self.cin))
+
     def packed(self, dtype):
         P = self.net.P
         key = (P.version, dtype)
         if self._packed[0] != key:
-            w = P.p(self.name + "_w")
-            if self.kind == "conv":
-                wf, wd = K.pack_weights(w, K.cpad(self.cin), K.cpad(self.cout), dtype)
-            else:   # equivalent conv: C = deconv out, K = deconv in -> the stored kernel is already its HWIO
-                wf, wd = K.pack_weights(w, K.cpad(self.cout), K.cpad(self.cin), dtype)
-            self._packed = (key, wf, wd)
+            if self.net.conv_units():
+                self.net.repack_all(dtype)               # every layer of the net in one launch
+            else:
+                Cp, Kp = self.pack_dims()
+                wf, wd = K.pack_weights(P.p(self.name + "_w"), Cp, Kp, dtype)
+                self._packed = (key, wf, wd)
         return self._packed[1], self._packed[2]
 
     def forward(self, x, residual=None):
@@ -295,9 +300,25 @@ class _Net:
         # set by a step that applies this net exactly twice (the cycle step): weight gradients of layers that support
         # it are deferred at the first backward and run with the second as one launch (_ConvUnit.backward)
         self.pair_wgrads = False
+        self._pack_tables = {}
 
     def conv_units(self):
         return ()
+
+    def repack_all(self, dtype):
+        """Pack the GEMM operands of every conv layer from the current parameters with ONE launch (all of them go stale
+        together at each optimizer step); buffers and the device-side item table are built once per dtype."""
+        units = self.conv_units()
+        st = self._pack_tables.get(dtype)
+        if st is None:
+            entries = [(self.P.p(u.name + "_w"),) + u.pack_dims() + (True, True) for u in units]
+            st = K.pack_weights_batch(entries, dtype, self.device)
+            self._pack_tables[dtype] = st
+        table, n, max_elems, bufs = st
+        K.repack_batch(table, n, max_elems, dtype)
+        key = (self.P.version, dtype)
+        for u, (wf, wd) in zip(units, bufs):
+            u._packed = (key, wf, wd)
 
     def flush_wgrads(self):
         for u in self.conv_units():
@@ -410,6 +431,9 @@ class Discriminator(_Net):
                       U("h32", "conv", stride=2, padding="VALID"),                # :303-305
                       U("h33", "conv", stride=1, padding="VALID")]                # :307-309
         self.h4 = _ConvUnit(self, "h4", "conv", stride=1, padding="SAME", norm=False, act=A.ACT_NONE)   # :311
+
+    def conv_units(self):
+        return list(self.units) + [self.h4]
 
     def forward(self, x, mask):
         """x internal (N,H,W,8); mask f32 (N,mh,mw,segment_class).  Returns (logits f32 (N,mh,mw,1), tape)."""

@@ -2569,6 +2569,181 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The same for STRIDE 2 (c2 / c3 and, with the operand roles swapped, the Conv2DTranspose layers d1 / d2,
+// module.py:236-242,254-260 backward).  One tap per block made these layers stream x nine times through L2
+// (1.5 GB per launch at the c2 shape, 11.6 TB/s: L2-bound at 131 us).  Here a stage is one dy row segment of 64 pixels:
+// the 3 x 129 input pixels it touches are staged once, de-interleaved by column parity (LDS slot = parity * 68 + column / 2),
+// so that a tap's stride-2 walk over columns is a unit-stride walk over LDS rows and the transposing reads of
+// conv3x3_wgrad_halo_kernel (and its swizzle) apply unchanged: tap column s reads plane s & 1 from row s >> 1.
+// -------------------------------------------------------------------------------------------------
+#define W9S_PITCH 136                                  // slots per halo row: 2 parity planes x 68 (65 / 64 used)
+#define W9S_XBYTES (3 * W9S_PITCH * 128)               // 52224
+#define W9S_DBYTES (64 * 256)                          // 16384
+#define W9S_STAGE (W9S_XBYTES + W9S_DBYTES)
+
+struct W9SArgs {
+    const char* x;       // (N,H,W,C)
+    const char* dy;      // (N,Ho,Wo,K)
+    float* ws;           // [splits][9*C][K] f32 slabs
+    int N, H, W, C, K, Ho, Wo, pad_t, pad_l;
+    int tiles, tiles_per_split;
+};
+
+__global__ __launch_bounds__(512) void conv3x3_wgrad_halo_s2_kernel(W9SArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages of { X halo [3][136][128 B], DY [64][256 B] }
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ct = wave & 3, kh = wave >> 2;
+    const int ktiles = a.K >> 7, otiles = (a.C >> 6) * ktiles;
+    int lid;
+    {
+        const int b = (int)blockIdx.x, nm = (int)gridDim.x;
+        const int q = nm >> 3, rr = nm & 7, xcd = b & 7;
+        lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
+    }
+    const int split = lid / otiles, tl = lid - split * otiles;
+    const int c0 = (tl / ktiles) * 64, n0 = (tl % ktiles) * 128;
+    const int t_beg = split * a.tiles_per_split;
+    const int t_end = min(a.tiles, t_beg + a.tiles_per_split);
+    const int tilesW = a.Wo / 64;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+    auto stage_tile = [&](int stg, int t) {
+        const int tw = t % tilesW, rest = t / tilesW;
+        const int ho = rest % a.Ho, n = rest / a.Ho;
+        const int w0 = tw * 64;
+        char* sX = smem + stg * W9S_STAGE;
+        char* sD = sX + W9S_XBYTES;
+        // dy: 16 wave-instructions of 4 pixels x 256 B; wave w issues 2w, 2w+1
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int d = wave * 2 + i;
+            const int px = d * 4 + (lane >> 4), pos = lane & 15;
+            const int key = wg2_key<bf16>(px) & 15;
+            const char* src = a.dy + ((((size_t)n * a.Ho + ho) * a.Wo + w0 + px) * a.K + n0) * 2 + ((pos ^ key) << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sD + d * 1024), 16, 0, 0);
+        }
+        // x halo: 3 rows x 17 wave-instructions of 8 slots; wave w issues q = w, w+8, ...
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int q = wave + 8 * i;
+            if (q >= 51) break;
+            const int k = q / 17, sg = q - 17 * k;
+            const int slot = sg * 8 + (lane >> 3), pos = lane & 7;      // 0..135
+            const int plane = slot >= 68 ? 1 : 0, j = slot - 68 * plane;
+            const int col = 2 * j + plane;                              // halo column 0..128
+            const int key = w9_xkey(k * W9S_PITCH + slot);
+            const int hi = 2 * ho - a.pad_t + k, wi = 2 * w0 - a.pad_l + col;
+            const bool ok = col <= 128 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            const char* src = ok ? a.x + ((((size_t)n * a.H + hi) * a.W + wi) * a.C + c0) * 2 + ((pos ^ key) << 4) : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sX + (k * W9S_PITCH + sg * 8) * 128), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, u = lane & 15, q4 = u >> 2, pp = u & 3;
+    // lane parts of the fragment addresses; halo classes by (b mod 16) = 8 * (r & 1) + 4 * (s & 1) + (s >> 1)
+    int doff[4][2], xoff[6][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int L = 8 * g + q4 + 4 * h;
+        const int kd = wg2_key<bf16>(L) & 15;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int col = kh * 64 + kt * 16 + 4 * pp;
+            doff[kt][h] = L * 256 + (((col >> 3) ^ kd) << 4) + (col & 7) * 2;
+        }
+#pragma unroll
+        for (int cls = 0; cls < 6; ++cls) {
+            const int sx = cls % 3;
+            const int bl = (cls / 3) * 8 + (sx & 1) * 4 + (sx >> 1);
+            const int col = ct * 16 + 4 * pp;
+            xoff[cls][h] = L * 128 + (((col >> 3) ^ w9_xkey(bl + L)) << 4) + (col & 7) * 2;
+        }
+    }
+    if (t_beg < t_end) stage_tile(0, t_beg);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int t = t_beg; t < t_end; ++t) {
+        const int cur = (t - t_beg) & 1;
+        if (t + 1 < t_end) stage_tile(cur ^ 1, t + 1);
+        const char* bX = smem + cur * W9S_STAGE;
+        const char* bD = bX + W9S_XBYTES;
+        auto ldD = [&](int kk, int kt) -> bf16x8 {
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bD + kk * (32 * 256) + doff[kt][0]));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bD + kk * (32 * 256) + doff[kt][1]));
+            return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        auto ldX = [&](int kk, int tap) -> bf16x8 {     // 32 dy pixels kk*32.. of the row <-> input columns 2*px + s, row r
+            const int r = tap / 3, sx = tap - 3 * r;
+            const int b = r * W9S_PITCH + (sx & 1) * 68 + (sx >> 1) + kk * 32;   // first LDS row of the fragment
+            const int cls = (r & 1) * 3 + sx;
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bX + b * 128 + xoff[cls][0]));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(bX + b * 128 + xoff[cls][1]));
+            return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        // 18 steps (k32-step kk, tap) of 4 MFMAs; x fragments rotate through 3 register sets, fetched two steps ahead
+        bf16x8 fd[2][4], fx[3];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fd[kk][j] = ldD(kk, j);
+        fx[0] = ldX(0, 0);
+        fx[1] = ldX(0, 1);
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            const int kk = i / 9, tap = i - 9 * kk;
+            if (i + 2 < 18) fx[(i + 2) % 3] = ldX((i + 2) / 9, (i + 2) % 9);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[kk][j], fx[i % 3], acc[tap][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    float* slab = a.ws + (size_t)split * 9 * a.C * a.K;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const size_t mr = (size_t)tap * a.C + c0 + ct * 16 + u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = n0 + kh * 64 + j * 16 + g * 4;
+            *reinterpret_cast<f32x4*>(slab + mr * a.K + k) = acc[tap][j];
+        }
+    }
+}
+
+static bool w9s_ok(const sgg_conv_desc* d) {
+    static int en = -1;
+    if (en < 0) { const char* e = getenv("SGG_W9S2"); en = e ? atoi(e) : 1; }
+    if (!en || !use_glds() || d->dtype != SGG_BF16 || d->pad_mode != SGG_PAD_ZERO) return false;
+    if (d->R != 3 || d->S != 3 || d->stride != 2 || d->H != 2 * d->Ho || d->W != 2 * d->Wo) return false;
+    if ((unsigned)d->pad_t > 1u || (unsigned)d->pad_l > 1u) return false;
+    // K >= 256 layers (c3 / d1) already run the 256x256 DMA kernel at the same speed (72 us); this kernel is for the
+    // 64 <-> 128 channel layers at full resolution, which were L2-bound at 131 us (89 us here)
+    if (d->K >= 256 && d->R * d->S * d->C >= 256) return false;
+    return d->Wo % 64 == 0 && d->C % 64 == 0 && d->K % 128 == 0;
+}
+static int w9s_tiles(const sgg_conv_desc* d) { return d->N * d->Ho * (d->Wo / 64); }
+static int w9s_splits(const sgg_conv_desc* d) {
+    const int otiles = (d->C / 64) * (d->K / 128), T = w9s_tiles(d);
+    int sp = otiles >= 256 ? 1 : 256 / otiles;
+    if (sp > T) sp = T;
+    if (sp > 256) sp = 256;
+    const int tps = (T + sp - 1) / sp;
+    return (T + tps - 1) / tps;
+}
+
 static bool w9_ok(const sgg_conv_desc* d) {
     static int en = -1;
     if (en < 0) { const char* e = getenv("SGG_W9"); en = e ? atoi(e) : 1; }
@@ -2607,6 +2782,7 @@ static int wgrad_splits(const sgg_conv_desc* d) {
     int64_t P = (int64_t)d->N * d->Ho * d->Wo;
     if (halo_wgrad_ok(d)) return halo_wgrad_blocks(d);               // one slab per persistent block
     if (w9_ok(d)) return w9_splits(d);
+    if (w9s_ok(d)) return w9s_splits(d);
     if (wgrad_use_v2(d)) {                                         // one 8-wave block per CU: ~256 blocks in all
         int64_t tiles = (int64_t)((d->R * d->S * d->C + 255) / 256) * ((d->K + 255) / 256);
         int64_t sp = 256 / tiles, maxs = (P + 127) / 128;
@@ -2674,6 +2850,24 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
     }
     if constexpr (sizeof(T) == 2) {
         if (w9_ok(d)) return run_w9(d, x, dy, nullptr, nullptr, dw, Cr, Kr, accumulate, ws, ws_bytes, s);   // 3x3 s1: x halo resident, all taps per block
+        if (w9s_ok(d)) {                                  // 3x3 s2: the same with a parity-de-interleaved halo
+            const int sp = w9s_splits(d);
+            size_t need9 = (size_t)sp * 9 * d->C * d->K * sizeof(float);
+            if (ws_bytes < need9 || !ws) return SGG_EWORKSPACE;
+            W9SArgs w;
+            w.x = (const char*)x; w.dy = (const char*)dy; w.ws = (float*)ws;
+            w.N = d->N; w.H = d->H; w.W = d->W; w.C = d->C; w.K = d->K; w.Ho = d->Ho; w.Wo = d->Wo; w.pad_t = d->pad_t; w.pad_l = d->pad_l;
+            w.tiles = w9s_tiles(d); w.tiles_per_split = (w.tiles + sp - 1) / sp;
+            static bool attr9s = false;
+            if (!attr9s) { hipFuncSetAttribute((const void*)conv3x3_wgrad_halo_s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W9S_STAGE); attr9s = true; }
+            hipLaunchKernelGGL(conv3x3_wgrad_halo_s2_kernel, dim3((unsigned)(sp * (d->C / 64) * (d->K / 128))), dim3(512), 2 * W9S_STAGE, s, w);
+            int rc9 = sgg_check_launch();
+            if (rc9) return rc9;
+            int64_t total9 = (int64_t)9 * Cr * (d->K / 4);
+            int blocks9 = (int)((total9 + 255) / 256); if (blocks9 > 4096) blocks9 = 4096;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks9), dim3(256), 0, s, (const float*)ws, dw, 9, d->C, d->K, Cr, Kr, sp, accumulate);
+            return sgg_check_launch();
+        }
     }
     int splits = wgrad_splits(d);
     a.pix_per_split = (int)align_up((size_t)((a.P + splits - 1) / splits), 64);

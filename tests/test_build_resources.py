@@ -22,6 +22,8 @@ MUST_NOT_SPILL = [
     "conv3x3_halo_gemm_kernelILi1ELb0E",                       # 3x3 data gradient, zero padding
     "conv3x3_halo_gemm_kernelILi1ELb1E",                       # 3x3 data gradient, REFLECT fold
     "conv3x3_wgrad_halo_kernel",                               # 3x3 weight gradient, all taps per block
+    "conv3x3_wgrad_halo_s2_kernel",                            # the same for stride 2
+    "deconv_s2_halo_kernel",                                   # stride-2 data gradient / Conv2DTranspose forward
     "conv_wgrad_glds_kernelIDF16bLb0E", "conv_wgrad_glds_kernelIDF16bLb1E",
     "conv_gemm_glds_kernelIDF16bLi0ELi256ELi256ELi2ELi8ELi128ELi2E",
     "conv_gemm_glds_kernelIDF16bLi1ELi256ELi256ELi2ELi8ELi128ELi2E",

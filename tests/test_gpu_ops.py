@@ -73,6 +73,8 @@ CONV_CASES = [
     ("halo3_same_tail", 3, 1, "SAME", 128, 192, 6, 256),          # zero padding fwd + dgrad, column tiles, tails
     ("s2halo_c2_like", 3, 2, "SAME", 64, 128, 16, 64),            # stride-2 data gradient, all parity classes per block
     ("s2halo_c3_like", 3, 2, "SAME", 128, 192, 32, 128),          # two output-channel tiles, 3 dy chunks, 2x2 pixel tiles
+    ("w9s2_c2_like", 3, 2, "SAME", 64, 128, 8, 128),              # stride-2 all-taps weight gradient (parity-split halo)
+    ("w9s2_two_ctiles", 3, 2, "SAME", 128, 128, 4, 256),          # two input-channel tiles, two column tiles per row
     ("w9_reflect", 3, 1, "REFLECT-1", 64, 128, 4, 64),            # all-taps halo wgrad (bf16): one output tile, 4 pixel tiles
     ("w9_same_multi", 3, 1, "SAME", 128, 256, 6, 128),            # zero padding, 2x2 output tiles, column tiles
 ]
@@ -192,7 +194,8 @@ def test_conv_wgrad_pair(sg):
 
 
 DECONV_CASES = [("d1_like", 16, 8, 6, 5), ("d2_like", 24, 16, 4, 8), ("wide", 128, 64, 5, 7), ("odd_c", 8, 3, 3, 3),
-                ("s2halo_d2_like", 128, 64, 8, 32), ("s2halo_d1_like", 256, 128, 16, 32)]
+                ("s2halo_d2_like", 128, 64, 8, 32), ("s2halo_d1_like", 256, 128, 16, 32),
+                ("w9s2_d2_like", 128, 64, 4, 64)]
 
 
 @pytest.mark.parametrize("dtype", DT, ids=["f32", "bf16"])

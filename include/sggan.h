@@ -210,6 +210,11 @@ int sgg_gradloss(const void* in, const void* target, const float* weight, int N,
  * theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps);   g is first multiplied by grad_scale (1/world for DP). */
 int sgg_adam(float* theta, const float* g, float* m, float* v, int64_t n, int t, float lr, float beta1, float beta2,
              float eps, float grad_scale, void* stream);
+/* The same update with t = *iterations + 1 read on the DEVICE (int64, the counterpart of Keras' `optimizer.iterations`
+ * variable); *iterations is incremented by a second 1-thread launch behind the update.  No host-side step state: the
+ * call can be captured into a HIP graph and replayed (the eager per-op dispatch of model.py:168 is what this removes). */
+int sgg_adam_iter(float* theta, const float* g, float* m, float* v, int64_t n, int64_t* iterations, float lr, float beta1,
+                  float beta2, float eps, float grad_scale, void* stream);
 
 /* ---- data side of the step ----
  * segment_class.py:60-70,95-97: colour -> class index, bit exact.  rgb: uint8 [n_pixels][channels>=3]. */

@@ -76,6 +76,7 @@ SIGNATURES = {
     "sgg_gradloss_workspace": (_sz, [_i, _i, _i, _i]),
     "sgg_gradloss": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "sgg_adam": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _vp]),
+    "sgg_adam_iter": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _vp]),
     "sgg_seg_class_map": (_i, [_vp, _i, _i64, _vp, _vp]),
     "sgg_seg_class_table": (_i, [_vp, _vp, _i]),
     "sgg_onehot_resample": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -1,6 +1,9 @@
 """Build libsggan.so (the C-ABI HIP library) in-tree for gfx950.
 
-    python sg-gan-tf2_amd/build.py [--force]
+    python sg-gan-tf2_amd/build.py [--force] [--lab]
+
+--lab builds libsggan_lab.so with -DSGG_LAB: the SGG_* kernel-selection / ablation environment switches and the
+sgg_debug_* exports used by tools/ (point SGG_LIB_PATH at it).  The shipped libsggan.so reads no environment.
 
 hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the GPU box with the repo snapshot.
 """
@@ -23,18 +26,20 @@ def _newer(dst, srcs):
     return all(os.path.getmtime(s) <= t for s in srcs)
 
 
-def build_lib(force=False, verbose=False):
+def build_lib(force=False, verbose=False, lab=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "sggan.h")]
+    OUT = os.path.join(HERE, "libsggan_lab.so" if lab else "libsggan.so")
     if not force and _newer(OUT, deps):
         return OUT
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     objs = []
+    flags = FLAGS + (["-DSGG_LAB"] if lab else [])
 
     def cc(src):
-        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        obj = os.path.join(HERE, "build", src.replace(".hip", ".lab.o" if lab else ".o"))
         if force or not _newer(obj, deps):
-            cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)
@@ -52,4 +57,4 @@ def build_lib(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose=True))
+    print(build_lib(force="--force" in sys.argv, verbose=True, lab="--lab" in sys.argv))

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/sggan.h"
 
 typedef __bf16 bf16;
@@ -92,4 +93,31 @@ __device__ inline uint32_t fdiv(uint32_t n, const FastDiv& f) {
 }
 
 static inline int sgg_check_launch() { return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ELAUNCH; }
+
+// Kernels that need more than 64 KB of dynamic LDS must have the attribute raised once PER DEVICE (a process may drive
+// several GPUs, from several host threads).  `done` holds one bit per device ordinal; setting the attribute twice is
+// harmless, so a relaxed race between two threads costs one redundant call, never a missing one.
+static inline int sgg_lds_attr(const void* kern, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return SGG_ELAUNCH;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return SGG_OK;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) { (void)hipGetLastError(); return SGG_ELAUNCH; }
+    done.fetch_or(bit, std::memory_order_release);
+    return SGG_OK;
+}
+#define SGG_LDS_ATTR(kern, bytes)                                                        \
+    do {                                                                                 \
+        static std::atomic<uint64_t> sgg_attr_done_{0};                                  \
+        int sgg_attr_rc_ = sgg_lds_attr((const void*)(kern), (int)(bytes), sgg_attr_done_); \
+        if (sgg_attr_rc_) return sgg_attr_rc_;                                           \
+    } while (0)
+
+// kernel-selection switches (defaults = the shipped configuration); see sgg_config() in conv.hip
+struct SggConfig {
+    int halo3 = 1, s2halo = 1, w9 = 1, w9s2 = 1, stem_dgrad_halo = 1, wgrad_rowfast = 1, glds = 1;
+    int in_fused_maxhw = -1;      // < 0: IN_FUSED_MAXHW of norm.hip
+    int ablate = 0;
+};
+const SggConfig& sgg_config();
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -23,6 +23,12 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifdef SGG_LAB
+#define SGG_ABLATE_OF(a) ((a).ablate)
+#else
+#define SGG_ABLATE_OF(a) 0      // the shipped kernels carry no ablation branches
+#endif
+
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_BORDER = 2 };   // BORDER: dgrad of the REFLECT border pixels only
 
 struct ConvArgs {
@@ -42,7 +48,7 @@ struct ConvArgs {
     int nact; float nleak;   // and the activation fused behind it
     float* partial;      // split-K (v2): f32 slabs [ksplit][pdst][DC]
     int ksplit;          // 1 = no split
-    int ablate;          // timing experiments only (SGG_ABLATE): 1 no in-loop DMA, 2 no LDS reads/MFMAs, 3 = 1 + no barrier,
+    int ablate;          // lab build only (SGG_ABLATE; always 0 and compiled out otherwise): 1 no in-loop DMA, 2 no LDS reads/MFMAs, 3 = 1 + no barrier,
                          // 5 prologue + epilogue only, 6 prologue only (results in DESIGN.md section 7)
     size_t pdst;         // destination pixels (slab stride)
     int N, H, W, C, K, R, S, stride, pad_t, pad_l, Ho, Wo, reflect;
@@ -58,6 +64,32 @@ struct WgradArgs {
     int P, pix_per_split;
     FastDiv dHW, dW;     // divide by Ho*Wo, Wo
 };
+
+// Kernel-selection switches.  The shipped library always returns the defaults below and never reads the environment;
+// only the lab build (-DSGG_LAB, `python sg-gan-tf2_amd/build.py --lab` -> libsggan_lab.so, used by tools/) lets
+// SGG_* environment variables override them for A/B timing and ablation runs.
+const SggConfig& sgg_config() {
+#ifdef SGG_LAB
+    static const SggConfig cfg = [] {
+        SggConfig c;
+        auto rd = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+        c.halo3 = rd("SGG_HALO3", c.halo3);                       // 3x3 stride-1 convs through the LDS-resident halo GEMM
+        c.s2halo = rd("SGG_S2HALO", c.s2halo);                    // stride-2 data gradient / transposed conv, all parity classes per block
+        c.w9 = rd("SGG_W9", c.w9);                                // all-taps 3x3 weight gradient
+        c.w9s2 = rd("SGG_W9S2", c.w9s2);                          // ... its stride-2 variant
+        c.stem_dgrad_halo = rd("SGG_STEM_DGRAD_HALO", c.stem_dgrad_halo);
+        c.wgrad_rowfast = rd("SGG_WGRAD_ROWFAST", c.wgrad_rowfast);
+        c.in_fused_maxhw = rd("SGG_IN_FUSED_MAXHW", c.in_fused_maxhw);
+        { const char* e = getenv("SGG_CONV_IMPL"); if (e && e[0] == 'r') c.glds = 0; }   // v1 register-staged GEMMs
+        c.ablate = rd("SGG_ABLATE", 0);                           // timing experiments: skips work, results are WRONG
+        return c;
+    }();
+    return cfg;
+#else
+    static const SggConfig cfg;
+    return cfg;
+#endif
+}
 
 static bool use_glds();
 
@@ -465,7 +497,7 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
     const int ktot = (nr * ns * cpv + CPR - 1) / CPR;
     const int kper = (ktot + a.ksplit - 1) / a.ksplit;
     const int kt0 = (int)blockIdx.y * kper;
-    const int ktiles = a.ablate >= 5 ? 0 : max(0, min(ktot, kt0 + kper) - kt0);   // ablate 5/6: no main loop
+    const int ktiles = SGG_ABLATE_OF(a) >= 5 ? 0 : max(0, min(ktot, kt0 + kper) - kt0);   // ablate 5/6: no main loop
     int t_cc, t_ri, t_si;
     { int q0 = lcc + kt0 * CPR; int ti = q0 / cpv; t_cc = q0 - ti * cpv; t_ri = ns ? ti / ns : nr; t_si = ns ? ti - t_ri * ns : 0; }
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
@@ -553,10 +585,10 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
     for (int kt = 0; kt < ktiles; ++kt) {
         const int cur = kt % NS;
         const bool refill = kt + NS - 1 < ktiles;
-        if (refill && (a.ablate == 0 || a.ablate == 2)) stage_tile((kt + NS - 1) % NS);
+        if (refill && (SGG_ABLATE_OF(a) == 0 || SGG_ABLATE_OF(a) == 2)) stage_tile((kt + NS - 1) % NS);
         const char* bP = smem + cur * STAGE + (wm * WM + frow) * BKB;
         const char* bQ = smem + cur * STAGE + BM * BKB + (wn * WN + frow) * BKB;
-        if (a.ablate != 2) {
+        if (SGG_ABLATE_OF(a) != 2) {
             // Fragment pipeline: all weight fragments of the tile up front, pixel fragments in groups of GJ that are
             // fetched one group ahead of the MFMAs that consume them, so the ~100-cycle LDS latency hides behind
             // GJ*NI MFMAs instead of stalling every 8 (what hipcc emitted for the plain j-loop).
@@ -599,12 +631,12 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
         }
         wait_tiles(refill);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (a.ablate < 3) __builtin_amdgcn_s_barrier();
+        if (SGG_ABLATE_OF(a) < 3) __builtin_amdgcn_s_barrier();
     }
 
     // bias of this lane's 4 output channels per channel tile, fetched once (a per-store load would put a full
     // L2 round trip in front of every one of the NI*MI stores)
-    if (a.ablate == 6) return;
+    if (SGG_ABLATE_OF(a) == 6) return;
     float bv[NI][4];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -710,8 +742,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     const int th = mt % tilesH;
     const int img = mt / tilesH;
     const int h0 = th * 2, w0 = tw * H3_TW;
-    const bool dbg_clk = a.ablate == 9 && lid == 0 && tid == 0;
-    const int abl = a.ablate == 9 ? 0 : a.ablate;    // 9 = full kernel + clock stamps
+    const bool dbg_clk = SGG_ABLATE_OF(a) == 9 && lid == 0 && tid == 0;
+    const int abl = SGG_ABLATE_OF(a) == 9 ? 0 : SGG_ABLATE_OF(a);    // 9 = full kernel + clock stamps
     if (dbg_clk) { g_dbg_clk[0] = clock64(); g_dbg_clk[1] = wall_clock64(); }
 
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
@@ -1186,9 +1218,8 @@ __global__ __launch_bounds__(512) void deconv_s2_halo_kernel(ConvArgs a, int tot
 }
 
 static bool s2halo_ok(const ConvArgs& a, bool is_bf16) {
-    static int en = -1;
-    if (en < 0) { const char* e = getenv("SGG_S2HALO"); en = e ? atoi(e) : 1; }
-    if (!en || !is_bf16 || !use_glds() || a.ksplit > 1 || a.ablate || a.reflect) return false;
+    const int en = sgg_config().s2halo;
+    if (!en || !is_bf16 || !use_glds() || a.ksplit > 1 || SGG_ABLATE_OF(a) || a.reflect) return false;
     if (a.R != 3 || a.S != 3 || a.stride != 2 || a.H != 2 * a.Ho || a.W != 2 * a.Wo) return false;
     if (a.pad_t != 0 || a.pad_l != 0) return false;     // TF 'SAME' with an even input pads bottom/right only
     return a.K % 64 == 0 && a.C % 64 == 0 && a.Wo % S2_TJ == 0 && a.Ho % S2_TI == 0;
@@ -1197,8 +1228,7 @@ static bool s2halo_ok(const ConvArgs& a, bool is_bf16) {
 template <int PT, int PL>
 static int launch_s2halo_p(const ConvArgs& a, hipStream_t s) {
     auto kern = deconv_s2_halo_kernel<PT, PL>;
-    static bool attr_done = false;
-    if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS); attr_done = true; }
+    SGG_LDS_ATTR(kern, S2_LDS);
     const int total = (int)((int64_t)a.N * (a.Ho / S2_TI) * (a.Wo / S2_TJ) * (a.C / 64));
     const int tpb = (total + 255) / 256;               // one persistent block per CU
     const int blocks = (total + tpb - 1) / tpb;
@@ -1210,8 +1240,7 @@ static int launch_s2halo(const ConvArgs& a, hipStream_t s) { return launch_s2hal
 // shapes the halo-resident kernel takes: 3x3, stride 1, pad 1 on a same-size output, bf16, 64 | source channels,
 // 128 | W, even H; REFLECT only forward (the REFLECT data gradient needs the mirrored border terms)
 static bool halo3_ok(const ConvArgs& a, int mode, bool is_bf16) {
-    static int en = -1;
-    if (en < 0) { const char* e = getenv("SGG_HALO3"); en = e ? atoi(e) : 1; }
+    const int en = sgg_config().halo3;
     if (!en || !is_bf16 || !use_glds() || a.ksplit > 1) return false;
     if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad_t != 1 || a.pad_l != 1 || a.Ho != a.H || a.Wo != a.W) return false;
     if (a.W % H3_TW || (a.H & 1) || a.H < 4) return false;
@@ -1224,8 +1253,7 @@ template <int MODE, bool FOLD, int STATS = 0>
 static int launch_halo3(const ConvArgs& a, hipStream_t s) {
     auto kern = conv3x3_halo_gemm_kernel<MODE, FOLD, STATS>;
     constexpr int lds = FOLD ? H3_LDS_FOLD : H3_LDS;
-    static bool attr_done = false;
-    if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
+    SGG_LDS_ATTR(kern, lds);
     const int DC = MODE == MODE_FWD ? a.K : a.C;
     const int64_t blocks = (int64_t)a.N * (a.H / 2) * (a.W / H3_TW) * ((DC + 255) / 256);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, a);
@@ -1414,8 +1442,7 @@ template <typename T>
 static int launch_halo_fwd(const sgg_conv_desc* d, const ConvArgs& a, hipStream_t s, int flip = 0) {
     size_t lds = 2 * (size_t)HALO_MAXR * 16 * 128 + (size_t)(HALO_TH + d->R - 1) * (HALO_TW + d->S - 1) * 128 + 1024;
     auto kern = conv_halo_fwd_kernel<T>;
-    static bool attr_done = false;
-    if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    SGG_LDS_ATTR(kern, 160 * 1024);
     dim3 grid((unsigned)(d->N * (d->H / HALO_TH) * (d->W / HALO_TW)));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a, flip);
     return sgg_check_launch();
@@ -1425,8 +1452,7 @@ static int launch_halo_fwd(const sgg_conv_desc* d, const ConvArgs& a, hipStream_
 // convolution over dy it is the head's shape (64 -> <= 16 channels), so it runs conv_halo_fwd_kernel with mirrored taps
 // and zero padding; REFLECT's MirrorPadGrad terms are then added to the border pixels by the MODE_BORDER launch
 static bool halo_dgrad_narrow_ok(const sgg_conv_desc* d) {
-    static int en = -1;
-    if (en < 0) { const char* e = getenv("SGG_STEM_DGRAD_HALO"); en = e ? atoi(e) : 1; }
+    const int en = sgg_config().stem_dgrad_halo;
     const int cch = d->dtype == SGG_BF16 ? 64 : 32;
     return en && use_glds() && d->C <= 16 && d->stride == 1 && d->R <= HALO_MAXR && d->S <= HALO_MAXR && d->R == d->S &&
            d->Ho == d->H && d->Wo == d->W && d->pad_t == (d->R - 1) / 2 && d->pad_l == (d->S - 1) / 2 &&
@@ -1692,8 +1718,7 @@ static int launch_halo_narrow_in(const sgg_conv_desc* d, const ConvArgs& a, int 
     const int ksteps = (d->R * d->S * cpv + 3) / 4;
     size_t lds = (size_t)64 * (((ksteps * 4) | 1) * 16) + (size_t)(HALO_TH + d->R - 1) * (HALO_TW + d->S - 1) * 8 * sizeof(T);
     auto kern = conv_halo_narrow_in_kernel<T>;
-    static bool attr_done = false;
-    if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    SGG_LDS_ATTR(kern, 160 * 1024);
     int ntiles = d->N * (d->H / HALO_TH) * (d->W / HALO_TW);
     int blocks = ntiles < 512 ? ntiles : 512;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, s, a, ntiles, flip);
@@ -2216,7 +2241,7 @@ static bool desc_ok(const sgg_conv_desc* d) {
 static ConvArgs make_args(const sgg_conv_desc* d, const void* src, const void* w, const float* bias, void* dst, int act, float leak) {
     ConvArgs a;
     a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst; a.addend = nullptr; a.fold = nullptr; a.stats = nullptr; a.nx = nullptr; a.nstats = nullptr; a.ngamma = nullptr; a.nbeta = nullptr; a.nact = 0; a.nleak = 0.f; a.partial = nullptr; a.ksplit = 1; a.pdst = 0;
-    { static int ab = -1; if (ab < 0) { const char* e = getenv("SGG_ABLATE"); ab = e ? atoi(e) : 0; } a.ablate = ab; }
+    a.ablate = sgg_config().ablate;
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S; a.stride = d->stride;
     a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.reflect = d->pad_mode == SGG_PAD_REFLECT;
     a.act = act; a.leak = leak;
@@ -2227,8 +2252,7 @@ template <typename T, int MODE, int BM, int BN, int WGM>
 static int launch_gemm_cfg(const ConvArgs& a, int64_t Mmax, int DC, int classes, hipStream_t s) {
     constexpr size_t lds = 2 * (BM + BN) * 128;
     auto kern = conv_gemm_kernel<T, MODE, BM, BN, WGM>;
-    static bool attr_done = false;
-    if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+    SGG_LDS_ATTR(kern, (int)lds);
     dim3 grid((unsigned)((Mmax + BM - 1) / BM), (unsigned)((DC + BN - 1) / BN), (unsigned)classes);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     return sgg_check_launch();
@@ -2273,8 +2297,7 @@ static int launch_glds_cfg(const ConvArgs& a, int64_t Mmax, int DC, int classes,
     constexpr int RPP = NW * (64 / (BKB / 16));
     constexpr size_t lds = (size_t)NS * (size_t)(BM + (BN + RPP - 1) / RPP * RPP) * BKB;
     auto kern = conv_gemm_glds_kernel<T, MODE, BM, BN, WGM, NW, BKB, NS>;
-    static bool attr_done = false;
-    if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+    SGG_LDS_ATTR(kern, (int)lds);
     const int64_t tilesN = (DC + BN - 1) / BN;
     int64_t blocks = (Mmax + BM - 1) / BM * tilesN;
     dim3 grid((unsigned)blocks, (unsigned)a.ksplit, (unsigned)classes);
@@ -2283,11 +2306,7 @@ static int launch_glds_cfg(const ConvArgs& a, int64_t Mmax, int DC, int classes,
 }
 
 // SGG_CONV_IMPL=reg selects the v1 register-staged kernels (kept for A/B runs); default = v2 direct-to-LDS
-static bool use_glds() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("SGG_CONV_IMPL"); v = (e && e[0] == 'r') ? 0 : 1; }
-    return v == 1;
-}
+static bool use_glds() { return sgg_config().glds != 0; }
 
 template <typename T, int MODE>
 static int launch_gemm(const ConvArgs& a, hipStream_t s) {
@@ -2319,18 +2338,11 @@ static int launch_gemm(const ConvArgs& a, hipStream_t s) {
     if constexpr (MODE != MODE_BORDER) {
         if (use_glds()) {
             // big square tiles (8 waves, 1 block per CU) when there is enough work to fill the chip with them
-            // A/B switch: SGG_GEMM_DEEP=1 selects 64-byte K-slices in a 4-stage ring (3 tiles in flight).  Measured
-            // on the residual conv (same box, interleaved): 2-stage 128-byte slices are 3-5 % faster, so they are
-            // the default -- the DMA latency is not what the waves wait for.
-            static int deep = -1;
-            if (deep < 0) { const char* e = getenv("SGG_GEMM_DEEP"); deep = e ? atoi(e) : 0; }
-            if (DC >= 256 && Mmax * ((DC + 255) / 256) >= 256 * 160) {
-                return deep ? launch_glds_cfg<T, MODE, 256, 256, 2, 8, 64, 4>(a, Mmax, DC, classes, s)
-                            : launch_glds_cfg<T, MODE, 256, 256, 2, 8, 128, 2>(a, Mmax, DC, classes, s);
-            }
+            // (a 4-stage ring of 64-byte K-slices was measured 3-5 % slower on the residual conv and is not built)
+            if (DC >= 256 && Mmax * ((DC + 255) / 256) >= 256 * 160)
+                return launch_glds_cfg<T, MODE, 256, 256, 2, 8, 128, 2>(a, Mmax, DC, classes, s);
             if (DC >= 128 && Mmax * ((DC + 127) / 128) >= 256 * 160)
-                return deep ? launch_glds_cfg<T, MODE, 256, 128, 4, 8, 64, 4>(a, Mmax, DC, classes, s)
-                            : launch_glds_cfg<T, MODE, 256, 128, 4, 8, 128, 2>(a, Mmax, DC, classes, s);
+                return launch_glds_cfg<T, MODE, 256, 128, 4, 8, 128, 2>(a, Mmax, DC, classes, s);
             // 128x128 with 8 waves (2 per SIMD, two blocks per CU): the 4-wave variant ran at one wave per SIMD with
             // nothing to cover its LDS latencies (D.h3 data gradient 86 -> 60 us, D.h2 forward 36 -> 23 us)
             if (DC >= 128) return launch_glds_cfg<T, MODE, 128, 128, 2, 8>(a, Mmax, DC, classes, s);
@@ -2724,8 +2736,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_s2_kernel(W9SArgs a) {
 }
 
 static bool w9s_ok(const sgg_conv_desc* d) {
-    static int en = -1;
-    if (en < 0) { const char* e = getenv("SGG_W9S2"); en = e ? atoi(e) : 1; }
+    const int en = sgg_config().w9s2;
     if (!en || !use_glds() || d->dtype != SGG_BF16 || d->pad_mode != SGG_PAD_ZERO) return false;
     if (d->R != 3 || d->S != 3 || d->stride != 2 || d->H != 2 * d->Ho || d->W != 2 * d->Wo) return false;
     if ((unsigned)d->pad_t > 1u || (unsigned)d->pad_l > 1u) return false;
@@ -2745,8 +2756,7 @@ static int w9s_splits(const sgg_conv_desc* d) {
 }
 
 static bool w9_ok(const sgg_conv_desc* d) {
-    static int en = -1;
-    if (en < 0) { const char* e = getenv("SGG_W9"); en = e ? atoi(e) : 1; }
+    const int en = sgg_config().w9;
     if (!en || !use_glds() || d->dtype != SGG_BF16) return false;
     if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->Ho != d->H || d->Wo != d->W) return false;
     return d->W % W9_TW == 0 && d->H % 2 == 0 && d->C % 64 == 0 && d->K % 128 == 0;
@@ -2766,8 +2776,7 @@ template <typename T, int BMW, int BNW, int WGM>
 static int launch_wgrad_cfg(WgradArgs& a, int splits, hipStream_t s) {
     constexpr size_t lds = 2 * 32 * (BMW + BNW) * sizeof(T);
     auto kern = conv_wgrad_kernel<T, BMW, BNW, WGM>;
-    static bool attr_done = false;
-    if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+    SGG_LDS_ATTR(kern, (int)lds);
     int Mrows = a.R * a.S * a.C;
     dim3 grid((unsigned)((Mrows + BMW - 1) / BMW), (unsigned)((a.K + BNW - 1) / BNW), (unsigned)splits);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
@@ -2813,8 +2822,7 @@ static int run_w9(const sgg_conv_desc* d, const void* x, const void* dy, const v
     w.N = d->N; w.H = d->H; w.W = d->W; w.C = d->C; w.K = d->K; w.reflect = d->pad_mode == SGG_PAD_REFLECT;
     w.tiles = w9_tiles(d) * (x2 ? 2 : 1);
     w.tiles_per_split = (w.tiles + sp - 1) / sp;
-    static bool attr9 = false;
-    if (!attr9) { hipFuncSetAttribute((const void*)conv3x3_wgrad_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W9_STAGE); attr9 = true; }
+    SGG_LDS_ATTR(conv3x3_wgrad_halo_kernel, 2 * W9_STAGE);
     hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel, dim3((unsigned)(sp * (d->C / 64) * (d->K / 128))), dim3(512), 2 * W9_STAGE, s, w);
     int rc9 = sgg_check_launch();
     if (rc9) return rc9;
@@ -2838,8 +2846,7 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
         a.pix_per_split = 0; a.dHW = make_fastdiv(1); a.dW = make_fastdiv(1);
         size_t lds = 512 * 16 * sizeof(T) + (size_t)(HALO_TH + d->R - 1) * (HALO_TW + d->S - 1) * 128 + 1024;
         auto kern = conv_halo_wgrad_kernel<T>;
-        static bool attr_done = false;
-        if (!attr_done) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+        SGG_LDS_ATTR(kern, 160 * 1024);
         hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, s, a, ntiles);
         int rc0 = sgg_check_launch();
         if (rc0) return rc0;
@@ -2858,8 +2865,7 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
             w.x = (const char*)x; w.dy = (const char*)dy; w.ws = (float*)ws;
             w.N = d->N; w.H = d->H; w.W = d->W; w.C = d->C; w.K = d->K; w.Ho = d->Ho; w.Wo = d->Wo; w.pad_t = d->pad_t; w.pad_l = d->pad_l;
             w.tiles = w9s_tiles(d); w.tiles_per_split = (w.tiles + sp - 1) / sp;
-            static bool attr9s = false;
-            if (!attr9s) { hipFuncSetAttribute((const void*)conv3x3_wgrad_halo_s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W9S_STAGE); attr9s = true; }
+            SGG_LDS_ATTR(conv3x3_wgrad_halo_s2_kernel, 2 * W9S_STAGE);
             hipLaunchKernelGGL(conv3x3_wgrad_halo_s2_kernel, dim3((unsigned)(sp * (d->C / 64) * (d->K / 128))), dim3(512), 2 * W9S_STAGE, s, w);
             int rc9 = sgg_check_launch();
             if (rc9) return rc9;
@@ -2878,16 +2884,11 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
     int rc;
     if (wgrad_use_v2(d)) {
         constexpr size_t lds = 2 * 2 * (size_t)(sizeof(T) == 2 ? 64 : 32) * 256 * sizeof(T);
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_done = true;
-        }
+        SGG_LDS_ATTR((conv_wgrad_glds_kernel<T, false>), lds);
+        SGG_LDS_ATTR((conv_wgrad_glds_kernel<T, true>), lds);
         dim3 grid((unsigned)(((d->R * d->S * d->C + 255) / 256) * ((d->K + 255) / 256) * splits));
         const int bkp = sizeof(T) == 2 ? 64 : 32;                      // pixels per stage (BKP in the kernel)
-        static int rf = -1;
-        if (rf < 0) { const char* e = getenv("SGG_WGRAD_ROWFAST"); rf = e ? atoi(e) : 1; }
+        const int rf = sgg_config().wgrad_rowfast;
         if (rf && d->Wo % bkp == 0) hipLaunchKernelGGL((conv_wgrad_glds_kernel<T, true>), grid, dim3(512), lds, s, a);
         else hipLaunchKernelGGL((conv_wgrad_glds_kernel<T, false>), grid, dim3(512), lds, s, a);
         rc = sgg_check_launch();
@@ -2903,7 +2904,8 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
 
 extern "C" {
 
-// debug aid (not part of include/sggan.h): timestamps left by the halo GEMM under SGG_ABLATE=9 and the wall-clock rate (kHz)
+#ifdef SGG_LAB
+// lab build only (not part of include/sggan.h): timestamps left by the halo GEMM under SGG_ABLATE=9 and the wall-clock rate (kHz)
 int sgg_debug_clocks(unsigned long long* out5) {
     if (!out5) return SGG_EINVAL;
     if (hipMemcpyFromSymbol(out5, HIP_SYMBOL(g_dbg_clk), 4 * sizeof(unsigned long long)) != hipSuccess) return SGG_ELAUNCH;
@@ -2918,12 +2920,13 @@ int sgg_debug_clocks(unsigned long long* out5) {
 int sgg_debug_occupancy(int* out, int cap) {
     int n = 0, v = 0;
     if (cap < 4) return SGG_EINVAL;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_gemm_glds_kernel<bf16, MODE_FWD, 256, 256, 2, 8, 64, 4>, 512, 131072); out[n++] = v;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_gemm_glds_kernel<bf16, MODE_DGRAD, 256, 256, 2, 8, 64, 4>, 512, 131072); out[n++] = v;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_gemm_glds_kernel<bf16, MODE_FWD, 256, 256, 2, 8, 128, 2>, 512, 131072); out[n++] = v;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_gemm_glds_kernel<bf16, MODE_DGRAD, 256, 256, 2, 8, 128, 2>, 512, 131072); out[n++] = v;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_gemm_kernel<bf16, MODE_FWD, 128, 128, 2>, 256, 65536); out[n++] = v;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_wgrad_kernel<bf16, 128, 128, 2>, 256, 32768); out[n++] = v;
     return n;
 }
+#endif  // SGG_LAB
 
 int sgg_pack_conv_weights(const float* w, int R, int S, int C, int K, int Cpad, int Kpad, int dtype, void* wf, void* wd, void* stream) {
     if (!w || R <= 0 || S <= 0 || C <= 0 || K <= 0 || Cpad < C || Kpad < K || Cpad % SGG_CPAD || Kpad % SGG_CPAD) return SGG_EINVAL;

@@ -306,6 +306,28 @@ __global__ __launch_bounds__(256) void adam_kernel(float* th, const float* g, fl
     }
 }
 
+// Same update with the step number read from a device-resident counter (Keras keeps `optimizer.iterations` as a variable
+// too): t = *iterations + 1.  The host never touches t, so the launch can sit inside a captured HIP graph and be
+// replayed.  lr_t is evaluated in double by one lane per block (same formula as the host path of sgg_adam).
+__global__ __launch_bounds__(256) void adam_iter_kernel(float* th, const float* g, float* m, float* v, int64_t n, const int64_t* iterations,
+                                                        float lr, float b1, float b2, float eps, float gs) {
+    __shared__ float lr_t_s;
+    if (threadIdx.x == 0) {
+        const double t = (double)(*iterations + 1);
+        lr_t_s = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+    }
+    __syncthreads();
+    const float lr_t = lr_t_s;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i] * gs;
+        float mi = b1 * m[i] + (1.f - b1) * gi;
+        float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        th[i] = th[i] - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+__global__ void counter_inc_kernel(int64_t* c) { *c += 1; }     // its own launch: every block of the update has read t by now
+
 // ---------------------------------------------------------------- colour -> class index (integer, bit exact)
 // segment_class.py:63-66: 21 colours -> {1..7}; default 0.  Keys are 24-bit (R<<16|G<<8|B).
 #define SGG_SEG_KEYS 0x804080, 0xF423E8, 0xFAAAA0, 0xE6968C, 0x464646, 0x66669C, 0xBE9999, 0xB4A5B4, 0x966464, 0x96785A, \
@@ -525,6 +547,19 @@ int sgg_adam(float* theta, const float* g, float* m, float* v, int64_t n, int t,
     if (n == 0) return SGG_OK;
     double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t));
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, n, (float)lr_t, beta1, beta2, eps, grad_scale);
+    return sgg_check_launch();
+}
+
+int sgg_adam_iter(float* theta, const float* g, float* m, float* v, int64_t n, int64_t* iterations, float lr, float beta1, float beta2,
+                  float eps, float grad_scale, void* stream) {
+    if (!theta || !g || !m || !v || !iterations || n < 0) return SGG_EINVAL;
+    if (n > 0) {
+        hipLaunchKernelGGL(adam_iter_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, n, (const int64_t*)iterations,
+                           lr, beta1, beta2, eps, grad_scale);
+        int rc = sgg_check_launch();
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, iterations);
     return sgg_check_launch();
 }
 

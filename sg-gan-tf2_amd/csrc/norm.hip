@@ -308,9 +308,8 @@ __global__ __launch_bounds__(256) void in_fused_small_kernel(const char* x, cons
 __global__ void in_param_grad_kernel(InParamGrad g, int C) { in_param_grad(g, C); }
 
 static bool in_use_fused(int64_t HW) {
-    static int mx = -1;
-    if (mx < 0) { const char* e = getenv("SGG_IN_FUSED_MAXHW"); mx = e ? atoi(e) : IN_FUSED_MAXHW; }
-    return HW <= mx;
+    const int mx = sgg_config().in_fused_maxhw;
+    return HW <= (mx >= 0 ? mx : IN_FUSED_MAXHW);
 }
 
 static int in_rows_per_block(int N, int64_t HW, int C, int vec) {

@@ -14,32 +14,47 @@ from . import _abi as A
 from . import kernels as K
 
 
+def _labels(x, dev):
+    t = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))
+    return t.to(dev).to(torch.int32).contiguous().view(-1)
+
+
+def _accumulate_hist(hist, label_true, label_pred, n_class):
+    """Adds one (true, predicted) label pair to the device-resident int64 confusion matrix ``hist`` (flat n_class^2)."""
+    lt, lp = _labels(label_true, hist.device), _labels(label_pred, hist.device)
+    assert lt.numel() == lp.numel()
+    A.check(A.lib().sgg_confusion_hist(K._p(lt), K._p(lp), lt.numel(), n_class, K._p(hist), K._s()), "confusion_hist")
+
+
 def _fast_hist(label_true, label_pred, n_class):
     """metric.py:18-24 -- (n_class, n_class) int64 confusion matrix; labels as int arrays/tensors of equal size."""
-    dev = "cuda"
-    lt = torch.as_tensor(np.asarray(label_true) if not isinstance(label_true, torch.Tensor) else label_true).to(dev).to(torch.int32).contiguous().view(-1)
-    lp = torch.as_tensor(np.asarray(label_pred) if not isinstance(label_pred, torch.Tensor) else label_pred).to(dev).to(torch.int32).contiguous().view(-1)
-    assert lt.numel() == lp.numel()
-    hist = torch.zeros(n_class * n_class, dtype=torch.int64, device=dev)
-    A.check(A.lib().sgg_confusion_hist(K._p(lt), K._p(lp), lt.numel(), n_class, K._p(hist), K._s()), "confusion_hist")
+    hist = torch.zeros(n_class * n_class, dtype=torch.int64, device="cuda")
+    _accumulate_hist(hist, label_true, label_pred, n_class)
     return hist.view(n_class, n_class).cpu().numpy()
 
 
 def scores(label_trues, label_preds, n_class):
-    """metric.py:27-47 -- same keys, same arithmetic on the accumulated histogram."""
-    hist = np.zeros((n_class, n_class))
+    """metric.py:27-47 -- the FCN score set (same keys).  The confusion matrix of ALL pairs is accumulated on the device
+    in one int64 buffer (exact, order independent) and read back once; the five scores are then ratios of its
+    per-class true-positive / ground-truth / prediction counts."""
+    hist = torch.zeros(n_class * n_class, dtype=torch.int64, device="cuda")
     for lt, lp in zip(label_trues, label_preds):
-        hist += _fast_hist(lt, lp, n_class)
+        _accumulate_hist(hist, lt, lp, n_class)
+    h = hist.view(n_class, n_class).cpu().numpy()
+    tp = np.diagonal(h).astype(np.float64)            # correctly labelled pixels per class
+    n_true = h.sum(axis=1).astype(np.float64)         # pixels whose ground truth is the class
+    n_pred = h.sum(axis=0).astype(np.float64)         # pixels predicted as the class
+    total = float(h.sum())
     with np.errstate(divide="ignore", invalid="ignore"):
-        acc = np.diag(hist).sum() / hist.sum()
-        acc_cls = np.nanmean(np.diag(hist) / hist.sum(axis=1))
-        iu = np.diag(hist) / (hist.sum(axis=1) + hist.sum(axis=0) - np.diag(hist))
-        valid = hist.sum(axis=1) > 0
-        mean_iu = np.nanmean(iu[valid])
-        freq = hist.sum(axis=1) / hist.sum()
-        fwavacc = (freq[freq > 0] * iu[freq > 0]).sum()
-    return {"Overall Acc": acc, "Mean Acc": acc_cls, "FreqW Acc": fwavacc, "Mean IoU": mean_iu,
-            "Class IoU": dict(zip(range(n_class), iu))}
+        iou = tp / (n_true + n_pred - tp)
+        seen = n_true > 0
+        share = n_true / total
+        out = {"Overall Acc": tp.sum() / total,
+               "Mean Acc": np.nanmean(tp / n_true),
+               "FreqW Acc": (share[share > 0] * iou[share > 0]).sum(),
+               "Mean IoU": np.nanmean(iou[seen]),
+               "Class IoU": {c: iou[c] for c in range(n_class)}}
+    return out
 
 
 def argmax_u8_labels(img, c_real=None):

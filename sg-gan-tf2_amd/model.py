@@ -15,7 +15,8 @@ import torch
 
 from . import _abi as A
 from . import kernels as K
-from .module import Discriminator, Generator
+from .graph import StepProgram
+from .module import Adam, Discriminator, Generator
 from .utils import ImagePool
 
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32, "fp32": torch.float32,
@@ -28,7 +29,7 @@ def default_args(**over):
     a = dict(batch_size=1, image_height=128, image_width=128, input_nc=3, output_nc=3, ngf=64, ndf=64,
              segment_class=34, beta1=0.5, lr=0.0002, L1_lambda=10.0, Lg_lambda=5.0, use_resnet=True, use_pix2pix=False,
              use_lsgan=True, ratio_gan2seg=10, max_size=50, phase="train", dataset_dir="city",
-             dtype="bf16", device="cuda", n_blocks=9, seed=19)
+             dtype="bf16", device="cuda", n_blocks=9, seed=19, graph=False)
     a.update(over)
     return SimpleNamespace(**a)
 
@@ -84,6 +85,18 @@ class sggan(object):
         self.pair_wgrads = bool(g("pair_wgrads", True))   # cycle step: one weight-gradient launch per layer for both applications of a G
         self.batch_d_real_fake = bool(g("batch_d_real_fake", True))   # pool mode: D(real) and D(pooled fakes) as one 2N pass
         self.gen_loss_metric, self.disc_loss_metric, self._metric_n = 0.0, 0.0, 0
+        # model.py:83-84 / 205-207: one Keras Adam per network (lr hard-coded 1e-3 on the live step; the cycle step
+        # uses --lr).  d_optim / g_optim are the reference's attribute names; the cycle step adds the other two.
+        lr = self.cycle_lr if self.cycle else self.lr
+        self.g_optim = Adam(self.generator, lr, self.beta1)
+        self.d_optim = Adam(self.discriminator, lr, self.beta1)
+        if self.cycle:
+            self.g_optim_BA = Adam(self.generator_BA, lr, self.beta1)
+            self.d_optim_B = Adam(self.discriminator_B, lr, self.beta1)
+        # HIP-graph replay of the step (graph.py): recorded at the first train_step after enable_graph()
+        self.use_graph = bool(g("graph", False))
+        self._program = None
+        self._static_in = {}
 
     # ------------------------------------------------------------------ data parallel (new capability)
     def enable_data_parallel(self, process_group=None):
@@ -95,10 +108,96 @@ class sggan(object):
         for net in self.networks():                             # identical replicas: broadcast rank 0's parameters
             self._dp.broadcast_(net.P.flat)
             net.P.version += 1
+        self._program = None                                    # a recorded step has no collectives in it: record again
         return self
 
+    def _host(self, fn):
+        """A host-side action at this point of the step (graph.StepProgram.host): called right away on the eager
+        path; while the step is being recorded it ends the current HIP-graph segment and is replayed between segments."""
+        return fn() if self._recording is None else self._recording.host(fn)
+
     def _allreduce(self, net):
-        return None if self._dp is None else self._dp.allreduce_async(net.P.grad)
+        """Launch the all-reduce of one network's gradient bucket; the returned handle's wait() orders the stream."""
+        if self._dp is None:
+            return None
+        h = _PendingReduce(self)
+        def launch():
+            h.work = self._dp.allreduce_async(net.P.grad)
+        self._host(launch)
+        return h
+
+    # ------------------------------------------------------------------ HIP-graph replay (graph.py)
+    _recording = None
+
+    def enable_graph(self, flag=True):
+        """Replay the step from captured HIP graphs instead of dispatching ~1 250 launches from Python each step."""
+        self.use_graph = bool(flag)
+        if not flag:
+            self._program = None
+        return self
+
+    _INPUTS_REF = ("real_A", "seg_A", "mask_A")
+    _INPUTS_CYCLE = ("real_A", "seg_A", "mask_A", "real_B", "seg_B", "mask_B")
+
+    def _convert_input(self, name, x):
+        if name.startswith("mask"):
+            m = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x, dtype=np.float32))
+            return m.to(device=self.device, dtype=torch.float32).contiguous()
+        return self._prep(x)
+
+    def _stage_inputs(self):
+        """Step inputs -> the static device buffers the recorded graphs read.  A buffer the caller fills in place (it is
+        what ``self.real_A`` etc. point at after the first graph step) costs nothing; anything else is converted and copied."""
+        names = self._INPUTS_CYCLE if self.cycle else self._INPUTS_REF
+        fresh = False
+        for n in names:
+            x = getattr(self, n)
+            buf = self._static_in.get(n)
+            if buf is not None and x is buf:
+                continue
+            t = self._convert_input(n, x)
+            if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+                self._static_in[n] = t.clone()
+                fresh = True
+            else:
+                buf.copy_(t)
+            setattr(self, n, self._static_in[n])
+        return fresh
+
+    def _graph_step(self):
+        if self.use_pool:
+            raise NotImplementedError("graph replay with the image pool: the pool's random swaps change the step's "
+                                      "launch sequence; run the pool step eagerly (enable_graph(False))")
+        if self._stage_inputs():
+            self._program = None                   # new shapes: record again
+        if self._program is None:
+            self._record()
+        self._program.replay()
+        return self.gen_loss, self.disc_loss
+
+    def _record(self):
+        """Warm up eagerly (kernel attributes, workspaces, weight-pack tables), put the parameters and optimizer state
+        back, then record ONE step without executing it."""
+        nets = self.networks()
+        keep = [(n.P.flat.clone(), n.P.m.clone(), n.P.v.clone(), n.P.iterations.clone()) for n in nets]
+        loss_keep = self._loss.clone()
+        hook, K.PROFILE = K.PROFILE, None          # event hooks cannot be recorded
+        try:
+            self._step_body()
+            torch.cuda.synchronize(self.device)
+            for n, (f, m, v, it) in zip(nets, keep):
+                n.P.flat.copy_(f); n.P.m.copy_(m); n.P.v.copy_(v); n.P.iterations.copy_(it)
+                n.P.version += 1                   # the recorded step starts by re-packing the conv weights
+            self._loss.copy_(loss_keep)
+            prog = StepProgram(self.device)
+            self._recording = prog
+            try:
+                prog.record(self._step_body)
+            finally:
+                self._recording = None
+            self._program = prog
+        finally:
+            K.PROFILE = hook
 
     # ------------------------------------------------------------------ the hot path
     def _prep(self, x):
@@ -108,12 +207,16 @@ class sggan(object):
     def train_step(self, args=None):
         """model.py:169-200.  Reads ``real_A, seg_A`` (N,H,W,3) in [0,1] and ``mask_A`` (N,mh,mw,C);
         writes ``fake_A, gen_loss, disc_loss``; updates G, D and both Adam states."""
+        if self.use_graph:
+            return self._graph_step()
+        return self._step_body()
+
+    def _step_body(self):
         if self.cycle:
             return self._train_step_cycle()
         G, D = self.generator, self.discriminator
         real, seg = self._prep(self.real_A), self._prep(self.seg_A)
-        mask = self.mask_A if isinstance(self.mask_A, torch.Tensor) else torch.as_tensor(np.asarray(self.mask_A, dtype=np.float32))
-        mask = mask.to(device=self.device, dtype=torch.float32).contiguous()
+        mask = self._convert_input("mask_A", self.mask_A)
         G.P.zero_grad()
         D.P.zero_grad()
 
@@ -145,10 +248,10 @@ class sggan(object):
         scale = 1.0 / self._world
         if hD is not None:
             hD.wait()
-        D.P.adam_step(self.lr, self.beta1, grad_scale=scale)               # :200
+        self.d_optim.apply_gradients(grad_scale=scale)                     # :200
         if hG is not None:
             hG.wait()
-        G.P.adam_step(self.lr, self.beta1, grad_scale=scale)               # :199
+        self.g_optim.apply_gradients(grad_scale=scale)                     # :199
         self._fake_internal = fake
         self.fake_A = _LazyUnpad(fake, self.output_c_dim)
         self.da_real, self.da_fake = da_real, da_fake
@@ -246,10 +349,10 @@ class sggan(object):
         hGab = self._allreduce(Gab)
 
         scale = 1.0 / self._world
-        for net, h in ((Da, hDa), (Db, hDb), (Gba, hGba), (Gab, hGab)):
+        for opt, h in ((self.d_optim, hDa), (self.d_optim_B, hDb), (self.g_optim_BA, hGba), (self.g_optim, hGab)):
             if h is not None:
                 h.wait()
-            net.P.adam_step(self.cycle_lr, self.beta1, grad_scale=scale)
+            opt.apply_gradients(grad_scale=scale)
         self.fake_A, self.fake_B = _LazyUnpad(fake_A, self.input_c_dim), _LazyUnpad(fake_B, C)
         self.cyc_A, self.cyc_B = _LazyUnpad(cyc_A, self.input_c_dim), _LazyUnpad(cyc_B, C)
         return self.gen_loss, self.disc_loss
@@ -339,6 +442,16 @@ class sggan(object):
             if getattr(args, "checkpoint_dir", None):
                 self.save(args.checkpoint_dir, epoch)
         return history
+
+
+class _PendingReduce:
+    """Handle of one gradient all-reduce: ``wait()`` orders the compute stream behind it (a host action, see _host)."""
+
+    def __init__(self, model):
+        self._model, self.work = model, None
+
+    def wait(self):
+        self._model._host(lambda: self.work.wait())
 
 
 class _LazyUnpad:

@@ -44,7 +44,18 @@ class ParamStore:
         z = lambda: torch.zeros(self.numel, dtype=torch.float32, device=self.device)
         self.flat, self.grad, self.m, self.v = z(), z(), z(), z()
         self.version = 0            # bumped whenever parameter values change (re-pack trigger)
-        self.step_count = 0         # Adam t
+        # Adam's step number lives on the device (Keras: the `optimizer.iterations` variable), so the update launch
+        # carries no host state and can be replayed from a captured HIP graph
+        self.iterations = torch.zeros(1, dtype=torch.int64, device=self.device)
+
+    @property
+    def step_count(self):
+        """Adam t (host copy of the device counter; synchronises -- checkpoint / test use only)."""
+        return int(self.iterations.item())
+
+    @step_count.setter
+    def step_count(self, t):
+        self.iterations.fill_(int(t))
 
     # views ------------------------------------------------------------------
     def _view(self, buf, name, padded):
@@ -105,9 +116,37 @@ class ParamStore:
 
     def adam_step(self, lr=1e-3, beta1=0.5, beta2=0.999, eps=1e-7, grad_scale=1.0):
         """tf.keras.optimizers.Adam.apply_gradients (model.py:199-200) over the whole network: one launch."""
-        self.step_count += 1
-        K.adam(self.flat, self.grad, self.m, self.v, self.step_count, lr, beta1, beta2, eps, grad_scale)
+        K.adam_iter(self.flat, self.grad, self.m, self.v, self.iterations, lr, beta1, beta2, eps, grad_scale)
         self.version += 1
+
+
+class Adam:
+    """``tf.keras.optimizers.Adam`` as the reference holds it in ``self.g_optim`` / ``self.d_optim`` (model.py:83-84,
+    199-200, 205-207), bound to one network's flat parameter store: the whole update is one fused launch."""
+
+    def __init__(self, net, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self.net, self.learning_rate, self.beta_1, self.beta_2, self.epsilon = net, learning_rate, beta_1, beta_2, epsilon
+
+    @property
+    def iterations(self):
+        return self.net.P.iterations
+
+    def apply_gradients(self, grads_and_vars=None, grad_scale=1.0):
+        """``optimizer.apply_gradients(zip(grads, net.trainable_variables))`` (model.py:199-200).  Called without
+        arguments it consumes the network's own gradient buffer (what ``sggan.train_step`` does); given (grad, var)
+        pairs, the gradients are first copied over that buffer -- ``var`` must be one of ``net.trainable_variables``."""
+        P = self.net.P
+        if grads_and_vars is not None:
+            names = P.names()
+            by_ptr = {v.data_ptr(): n for n, v in zip(names, self.net.trainable_variables)}
+            P.zero_grad()
+            for g, v in grads_and_vars:
+                name = by_ptr.get(v.data_ptr())
+                if name is None:
+                    raise ValueError("apply_gradients: variable does not belong to this optimizer's network")
+                if g is not None:
+                    P.g(name).copy_(torch.as_tensor(g, device=P.device).reshape(P.g(name).shape))
+        P.adam_step(self.learning_rate, self.beta_1, self.beta_2, self.epsilon, grad_scale)
 
 
 def generator_param_specs(gf_dim=64, in_c=3, out_c=3, n_blocks=9):

@@ -1,5 +1,7 @@
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("SGG_LIB_PATH", os.path.join(ROOT, "sg-gan-tf2_amd", "libsggan_lab.so"))   # sgg_debug_* live in the lab build
 import torch; torch.cuda.init()
 import sggan_amd
 L = ctypes.CDLL(sggan_amd.LIB_PATH)

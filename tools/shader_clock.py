@@ -1,9 +1,11 @@
 """Shader clock held by the residual-conv forward kernel while it runs (debug aid): the kernel timestamps one block with the
 shader-clock counter and the constant-rate wall clock (SGG_ABLATE=9), so cycles / wall time = the clock under load.
-    SGG_ABLATE=9 python tools/shader_clock.py"""
+    python sg-gan-tf2_amd/build.py --lab && SGG_ABLATE=9 python tools/shader_clock.py      (lab build: libsggan_lab.so)"""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 assert os.environ.get("SGG_ABLATE") == "9", "run with SGG_ABLATE=9"
+os.environ.setdefault("SGG_LIB_PATH", os.path.join(ROOT, "sg-gan-tf2_amd", "libsggan_lab.so"))   # ablation switches exist only there
 import torch
 import sggan_amd
 from sggan_amd import kernels as K, _abi as A

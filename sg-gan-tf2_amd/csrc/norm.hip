@@ -7,6 +7,13 @@
 //   bwd : partial (sum g, sum g*xhat)          -> finalize (+ dgamma, dbeta over n)               -> apply
 // Algorithmic bytes: fwd 2 reads + 1 write of the tensor, bwd 4 reads + 1 write.
 #include "common.h"
+#include <type_traits>
+
+// Per-thread accumulators of the statistics passes.  On the f32 parity path they are f64: the backward sums (sum g,
+// sum g*xhat) add a near-zero-mean field (the gradient that comes back through a SAME conv from another instance
+// norm), so the sum cancels to ~1e-3 of its terms and an f32 running sum over 64+ pixels is off by 1e-4 of the result --
+// visible against the float64 oracle (tools/diag_d_f32.py).  On the bf16 path the operands carry 8 bits: f32 is plenty.
+template <typename T> using InAcc = typename std::conditional<std::is_same<T, float>::value, double, float>::type;
 
 // pixels per partial-sum chunk: >= 64, and large enough that an image has at most ~128 chunks (the finalize kernels
 // walk the chunks of one channel serially: 2048 chunks cost 68 us on a 256x512x64 tensor, 128 chunks 5 us)
@@ -27,15 +34,16 @@ __global__ __launch_bounds__(256) void in_partial_kernel(const char* x, const ch
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int64_t p0 = (int64_t)chunk * rpc;
     const int64_t p1 = p0 + rpc < HW ? p0 + rpc : HW;
-    __shared__ float red[256][2 * VEC + 1];
+    using AccT = InAcc<T>;
+    __shared__ AccT red[256][2 * VEC + 1];
     // threads cover (pixel row, channel vector) pairs: cv = item % CV walks fastest
     for (int cvb = 0; cvb < CV; cvb += 256) {
         const int lanes = CV - cvb < 256 ? CV - cvb : 256;       // channel vectors handled in this sweep
         const int rows = 256 / lanes;                            // pixel rows in flight
         const int cv = cvb + (int)(threadIdx.x % lanes), prow = threadIdx.x / lanes;
-        float s1[VEC], s2[VEC];
+        AccT s1[VEC], s2[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) s1[e] = s2[e] = 0.f;
+        for (int e = 0; e < VEC; ++e) s1[e] = s2[e] = (AccT)0;
         float mu[VEC], rs[VEC], gm[VEC], bt[VEC];
         if (BWD && prow < rows) {
 #pragma unroll
@@ -52,7 +60,7 @@ __global__ __launch_bounds__(256) void in_partial_kernel(const char* x, const ch
                 ET<T>::unpack(ld16(x + off), xv);
                 if (!BWD) {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) { s1[e] += xv[e]; s2[e] += xv[e] * xv[e]; }
+                    for (int e = 0; e < VEC; ++e) { s1[e] += (AccT)xv[e]; s2[e] += (AccT)xv[e] * (AccT)xv[e]; }
                 } else {
                     float gv[VEC];
                     ET<T>::unpack(ld16(dy + off), gv);
@@ -60,7 +68,7 @@ __global__ __launch_bounds__(256) void in_partial_kernel(const char* x, const ch
                     for (int e = 0; e < VEC; ++e) {
                         float xh = (xv[e] - mu[e]) * rs[e];
                         float g = gv[e] * act_grad_from_pre(gm[e] * xh + bt[e], act, leak);
-                        s1[e] += g; s2[e] += g * xh;
+                        s1[e] += (AccT)g; s2[e] += (AccT)g * (AccT)xh;
                     }
                 }
             }
@@ -70,11 +78,11 @@ __global__ __launch_bounds__(256) void in_partial_kernel(const char* x, const ch
         // fixed-order combine over the pixel rows of each channel vector
         for (int item = threadIdx.x; item < lanes * VEC; item += 256) {
             int l = item / VEC, e = item % VEC;
-            float a = 0.f, b = 0.f;
+            AccT a = (AccT)0, b = (AccT)0;
             for (int r = 0; r < rows; ++r) { a += red[r * lanes + l][e]; b += red[r * lanes + l][VEC + e]; }
             int c = (cvb + l) * VEC + e;
             size_t o = (((size_t)n * chunks + chunk) * C + c) * 2;
-            partial[o] = a; partial[o + 1] = b;
+            partial[o] = (float)a; partial[o + 1] = (float)b;
         }
         __syncthreads();
     }
@@ -212,7 +220,8 @@ __global__ __launch_bounds__(256) void in_fused_small_kernel(const char* x, cons
     const int cvl = threadIdx.x % IN_CVB, prow = threadIdx.x / IN_CVB;
     const int cv = blockIdx.x * IN_CVB + cvl;
     const bool live = cv < CV;
-    __shared__ float red[256][2 * VEC + 1];
+    using AccT = InAcc<T>;
+    __shared__ AccT red[256][2 * VEC + 1];
     __shared__ float sh_a[IN_CVB * VEC], sh_b[IN_CVB * VEC];
 
     float mu[VEC], rs[VEC], gm[VEC], bt[VEC];
@@ -224,9 +233,9 @@ __global__ __launch_bounds__(256) void in_fused_small_kernel(const char* x, cons
             if (BWD) { mu[e] = stats[((size_t)n * C + c) * 2]; rs[e] = stats[((size_t)n * C + c) * 2 + 1]; }
         }
     }
-    float s1[VEC], s2[VEC];
+    AccT s1[VEC], s2[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) s1[e] = s2[e] = 0.f;
+    for (int e = 0; e < VEC; ++e) s1[e] = s2[e] = (AccT)0;
     if (live)
         for (int64_t p = prow; p < HW; p += ROWS) {
             const size_t off = (((size_t)n * HW + p) * C + (size_t)cv * VEC) * sizeof(T);
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(256) void in_fused_small_kernel(const char* x, cons
             ET<T>::unpack(ld16(x + off), xv);
             if (!BWD) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) { s1[e] += xv[e]; s2[e] += xv[e] * xv[e]; }
+                for (int e = 0; e < VEC; ++e) { s1[e] += (AccT)xv[e]; s2[e] += (AccT)xv[e] * (AccT)xv[e]; }
             } else {
                 float gv[VEC];
                 ET<T>::unpack(ld16(dy + off), gv);
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(256) void in_fused_small_kernel(const char* x, cons
                 for (int e = 0; e < VEC; ++e) {
                     const float xh = (xv[e] - mu[e]) * rs[e];
                     const float g = gv[e] * act_grad_from_pre(gm[e] * xh + bt[e], act, leak);
-                    s1[e] += g; s2[e] += g * xh;
+                    s1[e] += (AccT)g; s2[e] += (AccT)g * (AccT)xh;
                 }
             }
         }

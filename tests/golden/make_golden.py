@@ -19,6 +19,17 @@ Writes
                         inputs, forward outputs, losses, gradients, post-Adam parameters.
   oracle_full.json   -- oracle-generated checksums for the full-size networks at N=2,
                         128x128 (seeded parameters; losses, gradient norms, output stats).
+  mask_zoom_city.npz -- known-answer data for utils.py:158-165 + 197-199 (one_hot + scipy.ndimage.zoom): three
+                        of the reference's own class-index maps (datasets/city/trainA_seg_class/*.png, 1024x2048,
+                        34 labelIds) and what ``scipy.ndimage.zoom(one_hot(idx), (H/34/h, W/34/w, 1), mode="nearest")``
+                        returns for them at the 128x128 (4x4) and 512x256 (8x15) loader grids -- the reference's own
+                        call on the reference's own data, evaluated with the scipy installed here (1.15.x; the
+                        reference pinned 1.4.1 -- spline boundary handling for mode='nearest' changed in 1.6).
+  oracle_d256.npz    -- oracle-generated (PARITY UNPINNED) reference-mode step at 1x256x256 with the FULL-WIDTH
+                        discriminator (df_dim=64: 512-channel tail, D map 5x5, so every D gradient is non-zero) and
+                        a reduced generator (gf_dim=8, 2 blocks).  D's 8.79 M parameters are re-generated from the
+                        seed; its gradients / post-Adam parameters are stored as per-tensor norms, 4 random-sign
+                        projections and a strided sample of 4096 entries.
 """
 import json
 import os
@@ -144,7 +155,88 @@ def make_oracle_full():
     print("full step: gen_loss", r["gen_loss"], "disc_loss", r["disc_loss"])
 
 
+CITY = "/root/reference/datasets/city/trainA_seg_class"
+CITY_MAPS = ("aachen_000000.png", "aachen_000059.png", "aachen_000168.png")
+ZOOM_SIZES = ((128, 128), (256, 512))              # (image_height, image_width) -> 4x4 and 8x15 mask grids
+
+
+def make_mask_zoom():
+    from PIL import Image
+    out = {"names": np.array(CITY_MAPS), "sizes": np.array(ZOOM_SIZES)}
+    for i, f in enumerate(CITY_MAPS):
+        idx = np.array(Image.open(f"{CITY}/{f}"))
+        assert idx.dtype == np.uint8 and idx.ndim == 2 and idx.max() < 34
+        out[f"idx{i}"] = idx
+        hot = O.one_hot(idx, 34)                                       # utils.py:158-165
+        for (H, W) in ZOOM_SIZES:
+            z = O.zoom_mask_reference(hot, H, W)                       # utils.py:197-199, scipy as installed
+            assert z.shape == (round(H / 34), round(W / 34), 34) and set(np.unique(z).tolist()) <= {0, 1}
+            mine = O.mask_from_index(idx, 34, z.shape[0], z.shape[1])
+            print(f, (H, W), "grid", z.shape[:2], "cells where the nearest-index rule differs from zoom:", int((mine != z).any(-1).sum()))
+            out[f"zoom{i}_{H}x{W}"] = z.astype(np.uint8)
+    np.savez_compressed(os.path.join(HERE, "mask_zoom_city.npz"), **out)
+
+
+SIGNS = 4
+SAMPLE = 4096
+
+
+def tensor_digest(v):
+    """norm + SIGNS random-sign projections + a strided sample: enough to pin a multi-million-entry tensor in a small file."""
+    v = np.asarray(v, np.float64).ravel()
+    proj = []
+    for j in range(SIGNS):
+        s = np.random.default_rng(1000 + j).integers(0, 2, v.size).astype(np.float64) * 2 - 1
+        proj.append(float((v * s).sum()))
+    step = max(1, v.size // SAMPLE)
+    return np.array([np.sqrt((v * v).sum())] + proj), v[::step][:SAMPLE].astype(np.float32)
+
+
+def d256_inputs(seed=23):
+    """Seeded parameters + inputs of the oracle_d256 fixture (float32-representable), shared with the tests."""
+    rng = np.random.default_rng(seed)
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    PG = {k: f32(v) for k, v in O.init_params(O.generator_param_shapes(gf_dim=8, n_blocks=2), rng, perturb=0.1).items()}
+    PD = {k: f32(v) for k, v in O.init_params(O.discriminator_param_shapes(df_dim=64), rng, perturb=0.1).items()}
+    N, H, W = 1, 256, 256
+    real = f32(rng.integers(0, 256, (N, H, W, 3)) / 255.0)
+    seg = f32(rng.integers(0, 256, (N, H, W, 3)) / 255.0)
+    idx = rng.integers(0, 34, (N, 5, 5))
+    mask = np.stack([O.one_hot(i, 34) for i in idx]).astype(np.float64)
+    return PG, PD, real, seg, mask
+
+
+def make_oracle_d256():
+    PG, PD, real, seg, mask = d256_inputs()
+    r = O.train_step(PG, PD, real, seg, mask, n_blocks=2)
+    out = {"seed": np.array(23), "gen_loss": np.array(r["gen_loss"]), "disc_loss": np.array(r["disc_loss"]),
+           "fake_A": r["fake_A"].astype(np.float32), "da_real": r["da_real"], "da_fake": r["da_fake"],
+           "PD_crc32": np.array([zlib.crc32(b"".join(v.astype(np.float32).tobytes() for v in PD.values()))], np.uint32)}
+    for k in PG:
+        out["gG/" + k] = r["gG"][k].astype(np.float32)
+        out["newPG/" + k] = r["PG"][k].astype(np.float32)
+    # the same step by the independent PyTorch-CPU composition: float64 must agree with the NumPy oracle to rounding;
+    # its float32 run gives the inherent f32-vs-f64 distance per gradient tensor ("f32_floor", see the test)
+    import torch
+    from oracle import torch_restatement as T
+    t64 = T.RefStep(PG, PD, torch.float64, n_blocks=2).step(real, seg, mask, apply=False)
+    t32 = T.RefStep(PG, PD, torch.float32, n_blocks=2).step(real, seg, mask, apply=False)
+    for k in PD:
+        a, b, c = r["gD"][k], t64["gD"][k].numpy(), t32["gD"][k].numpy().astype(np.float64)
+        n = max(np.sqrt((a * a).sum()), 1e-30)
+        assert np.sqrt(((a - b) ** 2).sum()) < 1e-9 * n + 1e-12, ("oracle vs torch f64", k)
+        out["f32_floor/" + k] = np.array(max(np.sqrt(((a - c) ** 2).sum()) / n, np.abs(a - c).max() / max(np.abs(a).max(), 1e-30)))
+    for k in PD:
+        out["gD_digest/" + k], out["gD_sample/" + k] = tensor_digest(r["gD"][k])
+        out["newPD_digest/" + k], out["newPD_sample/" + k] = tensor_digest(r["PD"][k])
+        print("gD", k, "norm %.4e" % out["gD_digest/" + k][0])
+    np.savez_compressed(os.path.join(HERE, "oracle_d256.npz"), **out)
+    print("d256 step: gen_loss", r["gen_loss"], "disc_loss", r["disc_loss"])
+
+
 if __name__ == "__main__":
-    make_segclass()
-    make_oracle_small()
-    make_oracle_full()
+    which = sys.argv[1:] or ["segclass", "small", "full", "zoom", "d256"]
+    for name, fn in (("segclass", make_segclass), ("small", make_oracle_small), ("full", make_oracle_full),
+                     ("zoom", make_mask_zoom), ("d256", make_oracle_d256)):
+        if name in which:
+            fn()

@@ -310,6 +310,18 @@ def test_onehot_resample_bit_exact(sg):
         assert np.array_equal(got.sum(-1), np.ones((2, oh, ow)))
 
 
+def test_onehot_resample_matches_reference_zoom_on_reference_maps(sg):
+    """a12 pin on the GPU: sgg_onehot_resample on the reference's own class-index maps (datasets/city/trainA_seg_class)
+    vs the committed outputs of the reference's call (one_hot + scipy.ndimage.zoom, utils.py:158-165,197-199)."""
+    sc = sg.segment_class
+    z = np.load(os.path.join(G, "mask_zoom_city.npz"))
+    idx = np.stack([z[f"idx{i}"] for i in range(len(z["names"]))])
+    for H, W in z["sizes"]:
+        exp = np.stack([z[f"zoom{i}_{H}x{W}"] for i in range(len(idx))]).astype(np.float32)
+        got = sc.one_hot_mask(idx, exp.shape[1], exp.shape[2], 34).detach().cpu().numpy()
+        assert got.dtype == np.float32 and np.array_equal(got, exp), (H, W)
+
+
 @pytest.mark.parametrize("dtype", DT, ids=["f32", "bf16"])
 def test_mask_reduce(sg, dtype):
     from sggan_amd import kernels as K

@@ -141,6 +141,114 @@ def test_full_size_step_f32_matches_oracle_checksums(sg):
             assert abs(got[k] - e) < 2e-3 * max(e, 1e-8), (k, got[k], e)      # f32 vs f64 through 50+ layers
 
 
+def test_full_width_discriminator_backward_f32_matches_oracle_at_256(sg):
+    """Reference-mode step at 1x256x256 with the FULL-WIDTH discriminator (df_dim 64: 512-channel tail, split-K layers,
+    stride-2 VALID layers; D map 5x5 so none of D's gradients degenerates to zero as they do at 128x128) against the
+    float64 oracle fixture tests/golden/oracle_d256.npz: every D gradient tensor by norm, 4 random-sign projections and
+    a strided sample of 4096 entries; the same for the post-Adam D parameters; G's gradients element-wise."""
+    from tests.golden.make_golden import SIGNS, d256_inputs, tensor_digest
+    z = np.load(os.path.join(G, "oracle_d256.npz"))
+    PG, PD, real, seg, mask = d256_inputs(int(z["seed"]))
+    m = sg.sggan(sg.default_args(ngf=8, ndf=64, n_blocks=2, dtype="f32"))
+    m.generator.P.load(PG); m.discriminator.P.load(PD)
+    assert m.discriminator.P.n_real() == 8_791_970
+    m.real_A, m.seg_A, m.mask_A = real, seg, mask
+    m.train_step()
+    gl, dl = m.losses()
+    assert abs(gl - float(z["gen_loss"])) < 1e-5 * abs(float(z["gen_loss"])) and abs(dl - float(z["disc_loss"])) < 1e-5 * abs(float(z["disc_loss"]))
+    assert rel(m.fake_A.numpy(), z["fake_A"]) < 1e-4
+    assert rel(m.da_real.detach().cpu().numpy(), z["da_real"]) < 1e-4 and rel(m.da_fake.detach().cpu().numpy(), z["da_fake"]) < 1e-4
+    worst = {}
+    for label, got_all, skip in (("gD", m.discriminator.P.export(m.discriminator.P.grad), ("h0_b", "h4_b")),
+                                 ("newPD", m.discriminator.P.export(), ("h0_b", "h4_b"))):
+        for k, v in got_all.items():
+            if k.endswith("_b") and k not in skip:              # bias in front of an InstanceNorm: exactly 0 here, ~1e-16 in the oracle
+                if label == "gD":
+                    assert np.abs(v).max() == 0.0 and z["gD_digest/" + k][0] < 1e-9
+                continue
+            dg, smp = tensor_digest(v)
+            e_dg, e_smp = z[f"{label}_digest/{k}"], z[f"{label}_sample/{k}"]
+            norm = e_dg[0]
+            assert norm > 1e-3, (label, k, "degenerate expected tensor")       # the point of this fixture
+            if label == "gD":
+                # Element-wise the f32 path is within ~1e-6 of float64 EXCEPT behind
+                # LeakyReLU kinks: a pre-activation within f32 rounding of zero (a handful of the ~5 M activations of
+                # the two D passes) takes slope 1 on one side and 0.3 on the other, and that one element's difference
+                # spreads over every gradient below it (tools/diag_d_f32.py shows the single flipped element; the
+                # kink-free variant of this test, below, holds 2e-5 on every tensor).  Measured with the reference slope:
+                # 1e-3 ... 1.4e-2 of a tensor's norm on single projections / entries, depending on which elements flip.
+                # Hence 3e-2 here (norm: 5e-3) -- or twice what an independent f32 implementation (PyTorch-CPU,
+                # f32_floor) is off by, where that is more: h0's weight gradient sums a near-zero-mean field against an
+                # all-positive image (cancels to ~1e-3 of its terms).
+                tol = max(3e-2, 2.0 * float(z["f32_floor/" + k]))
+                assert abs(dg[0] - norm) / norm < max(5e-3, 2.0 * float(z["f32_floor/" + k])), (label, k, dg[0], norm)
+                errs = [abs(dg[0] - norm) / norm] + [abs(dg[1 + j] - e_dg[1 + j]) / norm for j in range(SIGNS)]
+                errs.append(np.abs(smp.astype(np.float64) - e_smp).max() / max(np.abs(e_smp).max(), 1e-30))
+                worst[k] = (max(errs), tol)
+            else:                                                   # parameters move by ~lr = 1e-3 per step
+                # Adam's first step is -lr*g/(|g|+eps): entries whose gradient is at rounding-noise level may flip sign
+                ge = z["gD_sample/" + k].astype(np.float64)          # same strided positions as the parameter sample
+                sig = np.abs(ge) > 1e-2 * np.abs(ge).max()          # (gradient noise here is ~1e-3 of the tensor: kink flips)
+                assert sig.mean() > 0.5 and np.abs(smp.astype(np.float64) - e_smp)[sig].max() < 2e-5, (label, k)
+    print("full-width D backward, worst relative error per tensor (error, tolerance):",
+          {k: (float("%.2e" % e), float("%.1e" % t)) for k, (e, t) in worst.items()})
+    assert all(e < t for e, t in worst.values()), {k: v for k, v in worst.items() if v[0] >= v[1]}
+    gG = m.generator.P.export(m.generator.P.grad)
+    for k, v in gG.items():
+        e = z["gG/" + k]
+        if k.endswith("_b") and k != "out_b":
+            continue
+        assert np.abs(e).max() > 0 and rel(v, e) < 2e-4, ("gG", k, rel(v, e))
+
+
+def test_full_width_discriminator_backward_kink_free_f32_is_tight(sg):
+    """Same full-width discriminator and inputs with LeakyReLU slope 1.0 (the activation becomes the identity, so no
+    gradient discontinuity is left anywhere): every conv data / weight gradient kernel, the split-K tail and every
+    instance-norm backward at full width against the live float64 oracle at 2e-5 of each tensor's norm.  (h0's
+    weight gradient cancels to ~1e-4 of its terms -- see above -- so its bound is 1e-6 of the same sum taken over
+    absolute values, the quantity f32 rounding actually scales with.)"""
+    from tests.golden.make_golden import d256_inputs
+    PG, PD, real, seg, mask = d256_inputs(23)
+    rng = np.random.default_rng(3)
+    dlog = rng.standard_normal((1, 5, 5, 1))
+    t = O.Tape()
+    VD = {k: O.Var(v, k) for k, v in PD.items()}
+    x = O.Var(seg)
+    out = O.discriminator(t, VD, x, mask, leak=1.0)
+    t.backward([(out, dlog)])
+    h0_out = t.ops[0][0]                                             # h0's conv output Var (its .g = gradient behind it)
+    ta = O.Tape()                                                    # sum |x|*|dy| for h0's weight gradient
+    wabs = O.Var(PD["h0_w"])
+    ya = O.conv2d(ta, O.Var(np.abs(seg)), wabs, O.Var(PD["h0_b"]), 2, "SAME")
+    ta.backward([(ya, np.abs(h0_out.g))])
+    D = sg.Discriminator(df_dim=64, dtype=torch.float32, device="cuda", seed=None, leak=1.0)
+    D.P.load(PD)
+    logits, tape = D.forward(D.to_internal(torch.as_tensor(seg, dtype=torch.float32).cuda()), torch.as_tensor(mask, dtype=torch.float32).cuda())
+    dx = D.backward(tape, torch.as_tensor(dlog, dtype=torch.float32).cuda(), want_dx=True)
+    assert rel(logits.cpu().numpy(), out.v) < 1e-5
+    l2 = lambda g, e: float(np.sqrt(((np.asarray(g, np.float64) - e) ** 2).sum()) / np.sqrt((e ** 2).sum()))
+    assert l2(dx.float().cpu().numpy()[..., :3], x.g) < 2e-5
+    errs = {}
+    for k, v in D.P.export(D.P.grad).items():
+        e = VD[k].g
+        if k.endswith("_b") and k not in ("h0_b", "h4_b"):
+            continue
+        if np.sqrt((e ** 2).sum()) < 1e-9:       # beta in front of a VALID conv + instance norm: a constant shift the
+            assert np.abs(v).max() < 1e-5       # next norm removes exactly -> zero gradient (h3, h31, h32 with slope 1)
+            continue
+        if k == "h0_w":
+            errs[k] = float(np.abs(v - e).max() / np.abs(wabs.g).max())
+            assert errs[k] < 1e-6, (k, errs[k])
+            continue
+        if k == "h0_b":                                               # plain sum of the same cancelling field
+            errs[k] = float(np.abs(v - e).max() / np.abs(h0_out.g).sum((0, 1, 2)).max())
+            assert errs[k] < 1e-6, (k, errs[k])
+            continue
+        errs[k] = l2(v, e)
+        assert errs[k] < 2e-5, (k, errs[k])
+    print("kink-free full-width D backward, relative L2 error per tensor:", {k: float("%.1e" % e) for k, e in errs.items()})
+
+
 def _rand_inputs(N, H, W, D, seed):
     g = torch.Generator().manual_seed(seed)
     real = torch.rand((N, H, W, 3), generator=g)
@@ -277,22 +385,60 @@ def test_cycle_step_small_f32_matches_oracle(sg):
         gl, dl = m.losses()
         assert abs(gl - r["g_loss"]) < 2e-5 * abs(r["g_loss"]) and abs(dl - r["d_loss"]) < 2e-5 * abs(r["d_loss"]), (gl, r["g_loss"], dl, r["d_loss"])
         assert rel(m.fake_B.numpy(), r["fake_B"]) < 1e-4 and rel(m.cyc_A.numpy(), r["cyc_A"]) < 2e-4
+        worst = {}
         for n, net in nets.items():
             got = net.P.export(net.P.grad)
             for k, e in r["grads"][n].items():
                 if np.abs(e).max() < 1e-9:
                     continue
-                # sign() in the L1 / gradient-sensitive terms makes the gradient piecewise constant in the fakes:
-                # f32-vs-f64 differences flip a few near-zero elements
-                assert rel(got[k], e) < 5e-3, (use_lsgan, n, k, rel(got[k], e))
+                # sign() in the L1 / gradient-sensitive terms and the ReLU / LeakyReLU kinks make the gradient piecewise
+                # constant in the activations: f32-vs-f64 differences flip a few near-zero elements, each of which
+                # moves single entries of the gradients below it -- so the bound is on the tensor (relative L2),
+                # with a looser one on the worst single entry
+                l2 = float(np.sqrt(((got[k] - e) ** 2).sum()) / np.sqrt((e ** 2).sum()))
+                worst[(use_lsgan, n, k)] = (l2, rel(got[k], e))
+                assert l2 < 5e-3 and rel(got[k], e) < 3e-2, (use_lsgan, n, k, l2, rel(got[k], e))
             new = net.P.export()
             for k, e in r["params"][n].items():
                 ge = r["grads"][n][k]
                 if np.abs(ge).max() < 1e-9:
                     continue
                 # Adam's first step is -lr*sign(g): elements whose gradient is at rounding-noise level may flip
-                sig = np.abs(ge) > 1e-3 * np.abs(ge).max()
+                sig = np.abs(ge) > 1e-2 * np.abs(ge).max()
                 assert np.abs(new[k] - e)[sig].max() < 2e-5, (n, k)
+        top = sorted(worst.items(), key=lambda kv: -kv[1][0])[:4]
+        print("cycle step vs oracle, largest gradient errors (relative L2, worst entry):", [(k[1:], "%.1e" % v[0], "%.1e" % v[1]) for k, v in top])
+
+
+def test_config3_cycle_step_at_its_stated_batch_8(sg):
+    """BASELINE configs[2] exactly as bench.py runs it: 512x256, batch 8, bf16, 9-block generators, cycle step (the
+    256-block = one-wave grids of the halo kernels only exist at N=8).  Two eager steps, then the same two steps as
+    HIP-graph replays on a second model: bitwise the same parameters; finite, sane losses; tanh-bounded images; and the
+    step is batch-consistent: images of samples 0..1 equal those of a batch-2 step on the same samples (every op is
+    per-sample in the forward pass)."""
+    args = dict(dtype="bf16", cycle=True)
+    inputs = lambda D, N: (_rand_inputs(N, 256, 512, D, 21), _rand_inputs(N, 256, 512, D, 22))
+    def run(graph, N=8, steps=2):
+        m = sg.sggan(sg.default_args(graph=graph, **args))
+        a, b = inputs(m.discriminator, 8)
+        m.real_A, m.seg_A, m.mask_A = (t[:N] for t in a)
+        m.real_B, m.seg_B, m.mask_B = (t[:N] for t in b)
+        first = None
+        for _ in range(steps):
+            m.train_step()
+            if first is None:
+                first = m.fake_B.tensor().clone()
+        return m, first
+    m, fakeB = run(False)
+    gl, dl = m.losses()
+    assert np.isfinite(gl) and np.isfinite(dl) and 0 < dl < 100 and 0 < gl < 200, (gl, dl)
+    f = m.fake_A.numpy()
+    assert f.shape == (8, 256, 512, 3) and np.isfinite(f).all() and np.abs(f).max() <= 1.0
+    mg, _ = run(True)
+    for a, b in zip(m.networks(), mg.networks()):
+        assert torch.equal(a.P.flat, b.P.flat) and torch.equal(a.P.m, b.P.m)
+    m2, fakeB2 = run(False, N=2, steps=1)
+    assert torch.equal(fakeB[:2], fakeB2)
 
 
 @pytest.mark.parametrize("cfg", [("config2: 256x256, batch 4, bf16, cycle step", 4, 256, 256, True),

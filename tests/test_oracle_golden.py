@@ -68,3 +68,21 @@ def test_oracle_full_fixture_is_wellformed():
     assert set(js["gD_norm"]) == {n for n, _ in O.discriminator_param_shapes()}
     # biases feeding an InstanceNorm get exactly zero gradient
     assert js["gG_norm"]["c2_b"] < 1e-9 and js["gD_norm"]["h1_b"] < 1e-9 and js["gG_norm"]["out_b"] > 0
+
+
+def test_mask_rule_matches_the_reference_zoom_on_reference_data():
+    """a12 pin: on three of the reference's own class-index maps (datasets/city/trainA_seg_class) the reference's call
+    ``scipy.ndimage.zoom(one_hot(idx), (H/34/h, W/34/w, 1), mode="nearest")`` (utils.py:197-199; outputs committed by
+    tests/golden/make_golden.py) equals one_hot of the align-corners nearest resample of the index map, at both loader grids."""
+    z = np.load(os.path.join(G, "mask_zoom_city.npz"))
+    cells = 0
+    for i in range(len(z["names"])):
+        idx = z[f"idx{i}"]
+        assert idx.shape == (1024, 2048) and idx.max() < 34
+        for H, W in z["sizes"]:
+            exp = z[f"zoom{i}_{H}x{W}"]
+            assert exp.shape == (round(H / 34), round(W / 34), 34) and (exp.sum(-1) == 1).all()
+            got = O.mask_from_index(idx, 34, exp.shape[0], exp.shape[1])
+            assert np.array_equal(got, exp.astype(np.float64))
+            cells += exp.shape[0] * exp.shape[1]
+    assert cells == 3 * (16 + 120)

@@ -90,40 +90,43 @@ def measured_traffic(kernel):
 
 
 class EventProfiler:
-    """Times selected launches with torch.cuda events on the current stream (the one kernels.py launches on)."""
+    """Times selected launches with HIP events on the stream the kernels are launched on, inside the timed region.
 
-    def __init__(self, res_hw=(64, 128), sample_every=6):
+    Events cannot be read back from inside a captured HIP graph (external event nodes abort on this ROCm/PyTorch), so in
+    graph mode the LAST steps of the timed region are dispatched eagerly -- same kernels, same order, same state, and the
+    same throughput (the eager step is GPU-bound too: 205 vs 204 images/s) -- and those are the steps whose launches are
+    timed.  ``mode``: "off", "live" (record), "calibrate" (an EMPTY event pair at the same places, in extra untimed
+    steps: the cost of the pair itself is taken off the spans)."""
+
+    # one launch in N per kernel family is timed: every pair is two marker packets in the launch queue
+    SAMPLE_EVERY = {"res_conv_fwd": 2, "res_conv_dgrad": 6, "res_conv_wgrad": 6, "res_conv_wgrad_pair": 6,
+                    "res_instnorm_fwd": 1, "res_instnorm_fwd_fused_stats": 6}
+
+    def __init__(self, res_hw=(64, 128)):
         self.records = {}
-        self.enabled = False
+        self.mode = "off"
         self.res_hw = tuple(res_hw)          # spatial size of the residual blocks (H/4, W/4)
-        # every event pair is two marker packets in the launch queue; timing all ~290 matching launches of a step
-        # cost 4 % of the step, so one launch in `sample_every` per kernel family is timed (>= 200 samples per run)
-        self.sample_every = max(1, int(sample_every))
         self.seen = {}
-        # calibration pass (after the timed region): the same sampled launches get an EMPTY event pair in front of them, so
-        # the cost of the pair itself (~5 us of queue markers) can be taken off the spans; what remains agrees with the
-        # per-kernel average of rocprofv3 --kernel-trace --stats on the same command (profiles/)
-        self.calibrating = False
         self.empty = []
 
     class _Span:
-        def __init__(self, store, empty=False):
-            self.s, self.e, self.store = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), store
-            self.is_empty = empty
+        def __init__(self, prof, store):
+            self.prof, self.store = prof, store
+            self.s, self.e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
         def start(self):
             self.s.record()
-            if self.is_empty:
+            if self.prof.mode == "calibrate":
                 self.e.record()
-                self.store.append((self.s, self.e))
+                self.prof.empty.append((self.s, self.e))
 
         def stop(self):
-            if not self.is_empty:
+            if self.prof.mode == "live":
                 self.e.record()
                 self.store.append((self.s, self.e))
 
     def __call__(self, name, key):
-        if not self.enabled:
+        if self.mode == "off":
             return None
         tag = None
         if name == "conv2d_fwd" and hasattr(key, "desc"):
@@ -150,11 +153,9 @@ class EventProfiler:
             return None
         k = self.seen.get(tag, 0)
         self.seen[tag] = k + 1
-        if k % self.sample_every:
+        if k % self.SAMPLE_EVERY.get(tag[0], 6):
             return None
-        if self.calibrating:
-            return self._Span(self.empty, empty=True)
-        return self._Span(self.records.setdefault(tag, []))
+        return self._Span(self, self.records.setdefault(tag, []))
 
     def overhead_ms(self):
         # median: an empty pair occasionally straddles a queue hiccup of tens of microseconds
@@ -164,13 +165,16 @@ class EventProfiler:
         """tag -> (mean span minus the event-pair overhead, samples, raw mean span)"""
         out, ov = {}, self.overhead_ms()
         for tag, evs in self.records.items():
+            if not evs:
+                continue
             ms = [s.elapsed_time(e) for s, e in evs]
             out[tag] = (max(float(np.mean(ms)) - ov, 1e-6), len(ms), float(np.mean(ms)))
         return out
 
 
-def cpu_baseline_cycle(H, W, seed):
-    """PyTorch-CPU f32 restatement of the cycle-mode step at N=1 (kind "port"): 1 warm-up + 1 timed step."""
+def cpu_baseline_cycle(H, W, seed, budget_s=70.0):
+    """PyTorch-CPU f32 restatement of the cycle-mode step at N=1 (kind "port"): 1 warm-up, then the median of up to 3 timed
+    steps -- as many as fit a wall-clock budget (one step of this shape takes ~15 s on the GPU node's host cores)."""
     from oracle import torch_restatement as T
     from oracle import sggan_oracle as O
     rng = np.random.default_rng(seed)
@@ -181,18 +185,25 @@ def cpu_baseline_cycle(H, W, seed):
     mk = lambda: np.stack([O.one_hot(rng.integers(0, 34, (mh, mw)), 34)]).astype(np.float32)
     inputs = (img(), img(), img(), img(), mk(), mk())
     S = T.CycleStep(P, torch.float32)
+    t0 = time.time()
     S.step(*inputs)
-    t1 = time.time()
-    S.step(*inputs)
-    dt = time.time() - t1
+    warm = time.time() - t0
+    times = []
+    while len(times) < 3 and (not times or (time.time() - t0) + float(np.median(times)) < budget_s):
+        t1 = time.time()
+        S.step(*inputs)
+        times.append(time.time() - t1)
+    dt = float(np.median(times))
     return {"value": 1.0 / dt, "unit": "images/sec", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"1 cycle-mode step (2G+2D) of N=1 {W}x{H} f32 (PyTorch-CPU restatement, oracle/torch_restatement.py "
-                      f"CycleStep; not TF2) after 1 warm-up; os.cpu_count()={os.cpu_count()}",
+            "sample": f"median of {len(times)} timed cycle-mode steps (2G+2D) of N=1 {W}x{H} f32 after 1 warm-up ({warm:.1f} s), as many "
+                      f"as fit a {budget_s:.0f} s budget (PyTorch-CPU restatement, oracle/torch_restatement.py CycleStep; not TF2); "
+                      f"step times {[round(t, 2) for t in times]} s; os.cpu_count()={os.cpu_count()}",
             "gflops": step_gflop_per_image(H, W, "cycle") / dt}
 
 
 def cpu_baseline(H, W, seed, max_seconds=30.0):
-    """The PyTorch-CPU f32 restatement of the reference-mode step at N=1 (kind "port"), median of up to 3 steps after 1 warm-up."""
+    """The PyTorch-CPU f32 restatement of the reference-mode step at N=1 (kind "port"), median of 3 steps after 1 warm-up
+    (fewer only if they do not fit the time budget)."""
     from oracle import torch_restatement as T
     from oracle import sggan_oracle as O
     rng = np.random.default_rng(seed)
@@ -247,6 +258,7 @@ def main():
     ap.add_argument("--mode", default="cycle", choices=["cycle", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--graph", type=int, default=1, help="1: replay the step from captured HIP graphs (default); 0: eager per-launch dispatch from Python")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -269,7 +281,7 @@ def main():
     from sggan_amd import kernels as K
     def make_model(mode):
         m = sggan_amd.sggan(sggan_amd.default_args(dtype=a.dtype, device=f"cuda:{local}", image_height=a.height,
-                                                   image_width=a.width, batch_size=a.batch, cycle=(mode == "cycle")))
+                                                   image_width=a.width, batch_size=a.batch, cycle=(mode == "cycle"), graph=bool(a.graph)))
         if dist is not None:
             m.enable_data_parallel()
         set_inputs(m, a.batch, a.height, a.width, 19 + rank)
@@ -279,6 +291,11 @@ def main():
 
     prof = EventProfiler((a.height // 4, a.width // 4))
     K.PROFILE = prof
+    timing = (rank == 0) and not a.no_kernel_timing
+    # graph mode: the last `eager_tail` steps of the timed region are dispatched eagerly so that their launches can be timed
+    # with events (EventProfiler); every rank does the same (the steps all-reduce)
+    eager_tail = 0 if (a.no_kernel_timing or not a.graph) else max(2, a.steps // 5)
+    eager_tail = min(eager_tail, a.steps)
 
     def barrier():
         torch.cuda.synchronize()
@@ -286,22 +303,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for i in range(a.warmup):
+        model.use_graph = bool(a.graph) and i < max(1, a.warmup - 1)      # one eager warm-up step too, when there is room
         model.train_step()
+    model.use_graph = bool(a.graph)
+    if a.graph and model._program is None:         # recording is not part of the timed region
+        model._stage_inputs(); model._record()
     barrier()
-    prof.enabled = (rank == 0) and not a.no_kernel_timing
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
+        if a.graph and i == a.steps - eager_tail:
+            model.use_graph = False
+        if timing and (not a.graph or i >= a.steps - eager_tail):
+            prof.mode = "live"
         model.train_step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if not a.no_kernel_timing:                    # calibration: two untimed steps (every rank: the steps all-reduce) with
-        prof.calibrating = True                   # empty event pairs at the sampled launches (rank 0, where prof is enabled)
+    if not a.no_kernel_timing:                    # calibration: two untimed eager steps (every rank: the steps all-reduce) with
+        model.use_graph = False                   # empty event pairs at the sampled launches (rank 0)
+        prof.mode = "calibrate" if timing else "off"
         for _ in range(2):
             model.train_step()
         barrier()
-        prof.calibrating = False
-    prof.enabled = False
+    prof.mode = "off"
+    model.use_graph = bool(a.graph)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -324,7 +349,10 @@ def main():
             "config": {"workload": f"BASELINE configs[2]: {what}, 9-block ResNet generators, "
                                    f"{a.width}x{a.height}, batch {a.batch}/GPU, {a.dtype} storage / f32 accumulate", "mode": a.mode,
                        "global_batch": a.batch * world, "height": a.height, "width": a.width, "parallelism": f"dp{world}",
-                       "gflop_per_image": gflop_img},
+                       "gflop_per_image": gflop_img,
+                       "dispatch": (f"HIP-graph replay of the recorded step (sggan_amd/graph.py) for {a.steps - eager_tail} of the {a.steps} timed "
+                                    f"steps, eager launches for the last {eager_tail} (the ones whose kernels are timed with events)"
+                                    if a.graph else "eager launches from Python")},
             "step_tflops": ips * gflop_img / 1e3,
             "step_frac_of_mfma_peak": ips * gflop_img / 1e3 / (PEAK_BF16_TFLOPS * world),
             "gen_loss": gl, "disc_loss": dl,
@@ -346,8 +374,9 @@ def main():
                                 "frac": k["tflops"] / PEAK_BF16_TFLOPS, "traffic": measured_traffic("res_conv_fwd"),
                                 "avg_launch_ms": k["avg_ms"], "launches_timed": k["launches"], "gflop_per_launch": k["gflop_per_launch"],
                                 "event_pair_overhead_ms": prof.overhead_ms(), "avg_span_ms_raw": k["avg_ms_raw_span"],
-                                "timing": "HIP events on the launch stream around 1 launch in 6 inside the timed region; the cost of an "
-                                          "empty event pair at the same places (measured in 2 extra untimed steps) is subtracted"}
+                                "timing": ("HIP events on the launch stream around 1 launch in 2 inside the timed region"
+                                           + (f" (its last {eager_tail} steps, which are dispatched eagerly: events cannot be read back from inside a replayed HIP graph)" if a.graph else "")
+                                           + "; the cost of an empty event pair at the same places (measured in 2 extra untimed steps) is subtracted")}
         else:
             line["roofline"] = None
         if "res_instnorm_fwd" in kt:
@@ -366,6 +395,7 @@ def main():
         if line.pop("_pending_reference"):
             # the literal reference step (1 G + 1 D) beside the headline, same shapes, short run
             K.PROFILE = None
+            model._program = None
             del model
             torch.cuda.empty_cache()
             ref = make_model("reference")

@@ -26,18 +26,20 @@ def _newer(dst, srcs):
     return all(os.path.getmtime(s) <= t for s in srcs)
 
 
-def build_lib(force=False, verbose=False, lab=False):
+def build_lib(force=False, verbose=False, lab=False, variant=None, defines=()):
+    """variant: build libsggan_<variant>.so with extra -D defines (A/B timing of kernel variants; SGG_LIB_PATH selects it)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "sggan.h")]
-    OUT = os.path.join(HERE, "libsggan_lab.so" if lab else "libsggan.so")
+    tag = variant or ("lab" if lab else None)
+    OUT = os.path.join(HERE, f"libsggan_{tag}.so" if tag else "libsggan.so")
     if not force and _newer(OUT, deps):
         return OUT
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     objs = []
-    flags = FLAGS + (["-DSGG_LAB"] if lab else [])
+    flags = FLAGS + (["-DSGG_LAB"] if lab else []) + list(defines)
 
     def cc(src):
-        obj = os.path.join(HERE, "build", src.replace(".hip", ".lab.o" if lab else ".o"))
+        obj = os.path.join(HERE, "build", src.replace(".hip", f".{tag}.o" if tag else ".o"))
         if force or not _newer(obj, deps):
             cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
@@ -57,4 +59,6 @@ def build_lib(force=False, verbose=False, lab=False):
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose=True, lab="--lab" in sys.argv))
+    var = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    print(build_lib(force="--force" in sys.argv, verbose=True, lab="--lab" in sys.argv, variant=var,
+                    defines=[a for a in sys.argv[1:] if a.startswith("-D")]))

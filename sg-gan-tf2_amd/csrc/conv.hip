@@ -382,6 +382,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[4] = {0u, 0u, 0u, 0u};
 // debug aid (SGG_ABLATE=9): shader-clock and wall-clock timestamps of one block of the halo GEMM, read by sgg_debug_clocks()
 __device__ unsigned long long g_dbg_clk[4];
+// lab build, SGG_ABLATE=8: shader-clock stamps of block 0, per wave, at six points of each of 16 mid-loop tiles
+// [wave][tile][point]: 0 loop top, 1 refill DMAs issued, 2 all MFMAs issued, 3 vmcnt(0) passed, 4 lgkmcnt(0) passed, 5 barrier passed
+__device__ unsigned long long g_dbg_phase[8][16][6];
 
 template <typename T, int MODE, int BM, int BN, int WGM, int NW, int BKB, int NS>
 __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
@@ -697,6 +700,9 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
 // next chunk.  K order: chunk-major, tap-minor.  Weight tiles: the same 2-stage DMA ring as above.
 // -------------------------------------------------------------------------------------------------
 #define H3_TW 128
+#ifndef H3_ISSUER_HALF
+#define H3_ISSUER_HALF 1                               // which half of the waves (0: waves 0-3, 1: waves 4-7) issues the main loop's DMAs
+#endif
 #define H3_PITCH 136                                   // halo row pitch in pixels (130 used; multiple of 8 = one DMA)
 #define H3_HALO_BYTES (4 * H3_PITCH * 128)
 #define H3_PATCH_ROWS 40                               // 2 tile rows x 2 sides x 9 taps = 36, rounded to whole DMAs
@@ -720,6 +726,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     char* sH = smem;                                   // halo [4][H3_PITCH][128 B]
     char* sB = smem + H3_HALO_BYTES;                   // 2 x [256][128 B]
     char* sPatch = smem + H3_LDS;                      // FOLD: 2 x [H3_PATCH_ROWS][128 B]
+    typedef __attribute__((address_space(3))) char lds_char;   // DMA destinations as LDS-space pointers from the start
+    lds_char* const lH = (lds_char*)smem;
+    lds_char* const lB = lH + H3_HALO_BYTES;
+    lds_char* const lPatch = lH + H3_LDS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar
     const int wm = wave / WGN, wn = wave % WGN;
@@ -743,7 +753,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     const int img = mt / tilesH;
     const int h0 = th * 2, w0 = tw * H3_TW;
     const bool dbg_clk = SGG_ABLATE_OF(a) == 9 && lid == 0 && tid == 0;
-    const int abl = SGG_ABLATE_OF(a) == 9 ? 0 : SGG_ABLATE_OF(a);    // 9 = full kernel + clock stamps
+    const int abl = SGG_ABLATE_OF(a) >= 8 ? 0 : SGG_ABLATE_OF(a);    // 8, 9 = full kernel + clock stamps
     if (dbg_clk) { g_dbg_clk[0] = clock64(); g_dbg_clk[1] = wall_clock64(); }
 
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
@@ -752,7 +762,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     const int hpos = lane & 7, hsub = lane >> 3;
     const bool mirror = MODE == MODE_FWD && a.reflect;                     // the data gradient always zero-pads dy
     const char* vrows = FOLD ? a.fold + (size_t)a.N * a.H * 18 * SC * 2 : nullptr;   // [N][2][W][SC] after the patches
-    auto load_halo_row = [&](int k, int chunk) {
+    // (Walking the channel chunks in a per-block rotated order -- so that the blocks of one XCD do not all want the
+    // same weight tile at the same moment -- measured 1-2 % slower: first-touch L2 misses are not what the tiles wait for.)
+    // (vw, nw): this wave acts as issuer vw of nw -- all 8 waves in the prologue, 4 issuer waves in the main loop
+    auto load_halo_row = [&](int k, int chunk, int vw, int nw) {
         int hi = h0 - 1 + k;
         bool rowok = true;
         if (mirror) hi = hi < 0 ? -hi : (hi >= a.H ? 2 * (a.H - 1) - hi : hi);
@@ -763,8 +776,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             if (h0 == a.H - 2 && k == 0) rowp = vrows + ((size_t)img * 2 + 1) * a.W * SC * 2 + chunk * 128;
         }
 #pragma unroll
-        for (int qi = 0; qi < 3; ++qi) {
-            const int q = wave + 8 * qi;
+        for (int qi = 0; qi < 5; ++qi) {
+            const int q = vw + nw * qi;
             if (q >= 17) break;
             const int hp = q * 8 + hsub;                                   // halo column 0..135
             int wi = w0 - 1 + hp;
@@ -774,44 +787,47 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             const int key = (((k * H3_PITCH + hp) >> 1) & 7);
             const char* src = ok ? rowp + (size_t)wi * SC * 2 + ((hpos ^ key) << 4) : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sH + (k * H3_PITCH + q * 8) * 128), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(lH + (k * H3_PITCH + q * 8) * 128), 16, 0, 0);
         }
     };
 
     // ---- FOLD: column patch, row pe = (tile row * 2 + side) * 9 + tap (halo tap order), 5 DMAs by waves 0..4
     const bool hasL = FOLD && tw == 0, hasR = FOLD && tw == tilesW - 1;
-    auto load_patch = [&](int chunk) {
-        if (!FOLD || wave >= H3_PATCH_ROWS / 8) return;
-        const int pe = wave * 8 + hsub;
-        const int tap_h = pe % 9, side = (pe / 9) & 1, tr = pe / 18;
-        const bool ok = pe < 36 && (side ? hasR : hasL);
-        const int key = (pe >> 1) & 7;
-        // a.fold first part: [N][H][2 sides][9 weight taps][SC]; halo tap t pairs with weight tap 8 - t
-        const char* src = ok ? a.fold + (((((size_t)img * a.H + h0 + tr) * 2 + side) * 9 + (8 - tap_h)) * SC + chunk * 64) * 2 + ((hpos ^ key) << 4)
-                             : zero;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(sPatch + ((chunk & 1) * H3_PATCH_ROWS + wave * 8) * 128), 16, 0, 0);
+    auto load_patch = [&](int chunk, int vw, int nw) {
+        if (!FOLD) return;
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            const int pw = vw + nw * qi;                                   // patch DMA 0..4
+            if (pw >= H3_PATCH_ROWS / 8) break;
+            const int pe = pw * 8 + hsub;
+            const int tap_h = pe % 9, side = (pe / 9) & 1, tr = pe / 18;
+            const bool ok = pe < 36 && (side ? hasR : hasL);
+            const int key = (pe >> 1) & 7;
+            // a.fold first part: [N][H][2 sides][9 weight taps][SC]; halo tap t pairs with weight tap 8 - t
+            const char* src = ok ? a.fold + (((((size_t)img * a.H + h0 + tr) * 2 + side) * 9 + (8 - tap_h)) * SC + chunk * 64) * 2 + ((hpos ^ key) << 4)
+                                 : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lPatch + ((chunk & 1) * H3_PATCH_ROWS + pw * 8) * 128), 16, 0, 0);
+        }
     };
 
-    // ---- weight-tile DMA (as in conv_gemm_glds_kernel): row = tid/8 + 64*i at position tid%8
-    const int srow0 = tid >> 3;
-    const int lcc = (tid & 7) ^ ((srow0 >> 1) & 7);
-    const char* qrow[QA];
-    unsigned qok = 0;
-#pragma unroll
-    for (int i = 0; i < QA; ++i) {
-        const int dc = n0 + srow0 + RPP * i;
-        qrow[i] = zero;
-        if (dc < DC) { qrow[i] = a.wmat + (size_t)dc * wrow * 2 + lcc * 16; qok |= 1u << i; }
-    }
-    auto load_w = [&](int stg, int chunk, int tap) {
+    // ---- weight-tile DMA: 32 wave-instructions of 8 rows x 128 B per tile; instruction d covers rows 8d .. 8d+7, lane l row
+    // 8d + l/8 at chunk position l%8 (swizzled by the row: key = (l/16 + 4(d&1)) & 7, i.e. the d-even key with bit 2 flipped)
+    const int wl = lane >> 3;
+    const char* wbase = a.wmat + (size_t)(n0 + wl) * wrow * 2;
+    const int wsw = ((lane & 7) ^ ((lane >> 4) & 7)) << 4;
+    const size_t wstride8 = (size_t)8 * wrow * 2;
+    auto load_w = [&](int stg, int chunk, int tap, int vw, int nw) {
         const int off = (tap * SC + chunk * 64) * 2;
-        char* sQ = sB + stg * (256 * 128);
+        lds_char* sQ = lB + stg * (256 * 128);
 #pragma unroll
-        for (int i = 0; i < QA; ++i) {
-            const char* src = qrow[i] + (((qok >> i) & 1u) ? off : 0);
+        for (int j = 0; j < 8; ++j) {
+            const int d = vw + nw * j;
+            if (d >= 32) break;
+            const bool ok = n0 + d * 8 + wl < DC;
+            const char* src = ok ? wbase + d * wstride8 + off + (wsw ^ ((d & 1) << 6)) : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sQ + (wave * 8 + RPP * i) * 128), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sQ + d * 8 * 128), 16, 0, 0);
         }
     };
 
@@ -826,27 +842,41 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
 
     // prologue: whole halo of chunk 0 + weight tile 0
 #pragma unroll
-    for (int k = 0; k < 4; ++k) load_halo_row(k, 0);
-    load_patch(0);
-    load_w(0, 0, MODE == MODE_FWD ? 0 : 8);
+    for (int k = 0; k < 4; ++k) load_halo_row(k, 0, wave, 8);
+    load_patch(0, wave, 8);
+    load_w(0, 0, MODE == MODE_FWD ? 0 : 8, wave, 8);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     const int ntiles = abl >= 5 ? 0 : nchunk * 9;
     int chunk = 0, tap = 0;                           // of the tile being multiplied
+#ifdef SGG_LAB
+    const bool stamp = SGG_ABLATE_OF(a) == 8 && lid == 0 && lane == 0;
+#define H3_STAMP(pt) do { if (stamp && t >= 8 && t < 24) g_dbg_phase[wave][t - 8][pt] = clock64(); } while (0)
+#else
+#define H3_STAMP(pt) do {} while (0)
+#endif
     for (int t = 0; t < ntiles; ++t) {
-        // refill: next weight tile, and the halo rows whose slots are free (see header)
-        if (abl == 0 || abl == 2) {
+        H3_STAMP(0);
+        // refill: next weight tile, and the halo rows whose slots are free (see header).  ISSUER WAVES: the CU's vector-memory
+        // path takes ~16 cycles per 1 KB DMA instruction, so the ~40 of a tile keep it busy for ~640 cycles; with every wave
+        // issuing its share at the head of the tile, all eight sat in issue stalls for that long with the matrix pipes idle
+        // (tools/halo_phases.py).  Now waves 4-7 issue ALL the DMAs while waves 0-3 -- their SIMD partners -- go straight to
+        // their MFMAs.  (Not the same as splitting each wave's issue in time: waves 4-7 issuing their own share half way
+        // through the tile measured 7 % slower.)
+        if ((abl == 0 || abl == 2) && (wave >> 2) == H3_ISSUER_HALF) {
+            const int vw = wave & 3;
             int ntap = tap + 1, nchk = chunk;
             if (ntap == 9) { ntap = 0; ++nchk; }
-            if (t + 1 < ntiles) load_w((t + 1) & 1, nchk, MODE == MODE_FWD ? ntap : 8 - ntap);
-            if (tap == 0 && chunk > 0) load_halo_row(2, chunk);
+            if (t + 1 < ntiles) load_w((t + 1) & 1, nchk, MODE == MODE_FWD ? ntap : 8 - ntap, vw, 4);
+            if (tap == 0 && chunk > 0) load_halo_row(2, chunk, vw, 4);
             if (tap == 3) {
-                if (chunk > 0) load_halo_row(3, chunk);
-                if (chunk + 1 < nchunk) { load_halo_row(0, chunk + 1); load_patch(chunk + 1); }
+                if (chunk > 0) load_halo_row(3, chunk, vw, 4);
+                if (chunk + 1 < nchunk) { load_halo_row(0, chunk + 1, vw, 4); load_patch(chunk + 1, vw, 4); }
             }
-            if (tap == 6 && chunk + 1 < nchunk) load_halo_row(1, chunk + 1);
+            if (tap == 6 && chunk + 1 < nchunk) load_halo_row(1, chunk + 1, vw, 4);
         }
+        H3_STAMP(1);
         const int r = tap / 3, sx = tap - 3 * r;
         // halo offset (r, sx) pairs with weight tap (r, sx) forward and with the flipped tap (2-r, 2-sx) = 8 - tap in
         // the data gradient, so both modes walk the halo rows in the same order (the refill schedule relies on it)
@@ -896,9 +926,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
                             __builtin_bit_cast(bf16x8, fw[kk][i]), __builtin_bit_cast(bf16x8, fp[g & 1][jj]), acc[i][jb + jj], 0, 0, 0);
             }
         }
+        H3_STAMP(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        H3_STAMP(3);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        H3_STAMP(4);
         if (abl < 3) __builtin_amdgcn_s_barrier();
+        H3_STAMP(5);
         if (++tap == 9) { tap = 0; ++chunk; }
     }
 
@@ -2905,6 +2939,11 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
 extern "C" {
 
 #ifdef SGG_LAB
+// lab build only: the per-phase stamps of SGG_ABLATE=8 (768 values)
+int sgg_debug_phases(unsigned long long* out768) {
+    if (!out768) return SGG_EINVAL;
+    return hipMemcpyFromSymbol(out768, HIP_SYMBOL(g_dbg_phase), sizeof(g_dbg_phase)) == hipSuccess ? SGG_OK : SGG_ELAUNCH;
+}
 // lab build only (not part of include/sggan.h): timestamps left by the halo GEMM under SGG_ABLATE=9 and the wall-clock rate (kHz)
 int sgg_debug_clocks(unsigned long long* out5) {
     if (!out5) return SGG_EINVAL;

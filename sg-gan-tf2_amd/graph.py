@@ -31,7 +31,9 @@ class StepProgram:
         self._g = torch.cuda.CUDAGraph()
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()     # one private pool shared by every segment of the step
-        self._g.capture_begin(pool=self._pool)
+        # thread_local: only THIS thread's unsafe calls invalidate the capture -- RCCL's watchdog thread polls its events
+        # with HIP calls of its own while a process group is alive, and must not abort a recording
+        self._g.capture_begin(pool=self._pool, capture_error_mode="thread_local")
 
     def _close(self):
         self._g.capture_end()

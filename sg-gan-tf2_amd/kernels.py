@@ -58,6 +58,15 @@ def _prof(name, key):
     return PROFILE(name, key) if PROFILE is not None else None
 
 
+# Host-side actions in step order (graph.StepProgram.host): while a step is being recorded into HIP graphs the recorder is
+# installed here; an action then ends the current graph segment and is replayed between segments.  Otherwise it just runs.
+_RECORDER = None
+
+
+def host(fn):
+    return fn() if _RECORDER is None else _RECORDER.host(fn)
+
+
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     """Per-device scratch buffer shared by all launches (single stream => in-order reuse is safe)."""

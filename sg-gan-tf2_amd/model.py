@@ -114,7 +114,7 @@ class sggan(object):
     def _host(self, fn):
         """A host-side action at this point of the step (graph.StepProgram.host): called right away on the eager
         path; while the step is being recorded it ends the current HIP-graph segment and is replayed between segments."""
-        return fn() if self._recording is None else self._recording.host(fn)
+        return K.host(fn)
 
     def _allreduce(self, net):
         """Launch the all-reduce of one network's gradient bucket; the returned handle's wait() orders the stream."""
@@ -127,8 +127,6 @@ class sggan(object):
         return h
 
     # ------------------------------------------------------------------ HIP-graph replay (graph.py)
-    _recording = None
-
     def enable_graph(self, flag=True):
         """Replay the step from captured HIP graphs instead of dispatching ~1 250 launches from Python each step."""
         self.use_graph = bool(flag)
@@ -181,7 +179,7 @@ class sggan(object):
         nets = self.networks()
         keep = [(n.P.flat.clone(), n.P.m.clone(), n.P.v.clone(), n.P.iterations.clone()) for n in nets]
         loss_keep = self._loss.clone()
-        hook, K.PROFILE = K.PROFILE, None          # event hooks cannot be recorded
+        hook, K.PROFILE = K.PROFILE, None          # timing hooks (bench.py) record events: not while recording
         try:
             self._step_body()
             torch.cuda.synchronize(self.device)
@@ -190,11 +188,11 @@ class sggan(object):
                 n.P.version += 1                   # the recorded step starts by re-packing the conv weights
             self._loss.copy_(loss_keep)
             prog = StepProgram(self.device)
-            self._recording = prog
+            K._RECORDER = prog
             try:
                 prog.record(self._step_body)
             finally:
-                self._recording = None
+                K._RECORDER = None
             self._program = prog
         finally:
             K.PROFILE = hook

@@ -210,10 +210,11 @@ int sgg_gradloss(const void* in, const void* target, const float* weight, int N,
  * theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps);   g is first multiplied by grad_scale (1/world for DP). */
 int sgg_adam(float* theta, const float* g, float* m, float* v, int64_t n, int t, float lr, float beta1, float beta2,
              float eps, float grad_scale, void* stream);
-/* The same update with t = *iterations + 1 read on the DEVICE (int64, the counterpart of Keras' `optimizer.iterations`
- * variable); *iterations is incremented by a second 1-thread launch behind the update.  No host-side step state: the
- * call can be captured into a HIP graph and replayed (the eager per-op dispatch of model.py:168 is what this removes). */
-int sgg_adam_iter(float* theta, const float* g, float* m, float* v, int64_t n, int64_t* iterations, float lr, float beta1,
+/* The same update with the step number kept on the DEVICE: `state` is int64[2] -- state[0] is the counterpart of Keras'
+ * `optimizer.iterations` variable (t = state[0] + 1 is used and state[0] incremented), state[1] is scratch.  Two launches
+ * (a 1-thread one that evaluates lr_t, then the update); no host-side step state, so the call can be captured into a HIP
+ * graph and replayed (the eager per-op dispatch of model.py:168 is what this removes). */
+int sgg_adam_iter(float* theta, const float* g, float* m, float* v, int64_t n, int64_t* state, float lr, float beta1,
                   float beta2, float eps, float grad_scale, void* stream);
 
 /* ---- data side of the step ----

@@ -115,7 +115,7 @@ static inline int sgg_lds_attr(const void* kern, int bytes, std::atomic<uint64_t
 
 // kernel-selection switches (defaults = the shipped configuration); see sgg_config() in conv.hip
 struct SggConfig {
-    int halo3 = 1, s2halo = 1, w9 = 1, w9s2 = 1, stem_dgrad_halo = 1, wgrad_rowfast = 1, glds = 1;
+    int halo3 = 1, s2halo = 1, w9 = 1, w9s2 = 1, stem_dgrad_halo = 1, wgrad_rowfast = 1, glds = 1, n7 = 1;
     int in_fused_maxhw = -1;      // < 0: IN_FUSED_MAXHW of norm.hip
     int ablate = 0;
 };

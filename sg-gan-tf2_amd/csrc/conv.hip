@@ -78,6 +78,7 @@ const SggConfig& sgg_config() {
         c.w9 = rd("SGG_W9", c.w9);                                // all-taps 3x3 weight gradient
         c.w9s2 = rd("SGG_W9S2", c.w9s2);                          // ... its stride-2 variant
         c.stem_dgrad_halo = rd("SGG_STEM_DGRAD_HALO", c.stem_dgrad_halo);
+        c.n7 = rd("SGG_N7", c.n7);                                // 7x7 64<->3 layers: (channel, tap column) in the GEMM N dimension
         c.wgrad_rowfast = rd("SGG_WGRAD_ROWFAST", c.wgrad_rowfast);
         c.in_fused_maxhw = rd("SGG_IN_FUSED_MAXHW", c.in_fused_maxhw);
         { const char* e = getenv("SGG_CONV_IMPL"); if (e && e[0] == 'r') c.glds = 0; }   // v1 register-staged GEMMs
@@ -1464,6 +1465,529 @@ __global__ __launch_bounds__(512) void conv_halo_fwd_kernel(ConvArgs a, int flip
             } else *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
         }
     }
+}
+
+// -------------------------------------------------------------------------------------------------
+// 7x7, 64 -> 3 channels at full resolution (bf16): the generator head forward (module.py:262-264) and, with mirrored
+// taps, the main part of the stem's data gradient (module.py:230-232 backward).
+//
+// conv_halo_fwd_kernel above puts the 3 output channels in a 16-wide MFMA dimension (13 of 16 columns wasted) and
+// reads one LDS fragment per MFMA.  Here the GEMM N dimension carries (output channel, tap COLUMN) = 3 x 7 = 21 -> 32
+// and only the tap ROW stays in the reduction:
+//     D[q][(co, s)] = sum_{r, c} halo[y + r][q][c] * w[r][s][c][co]          (q = halo column, K = 7 x 64)
+//     out[y][p][co] = sum_s D[p + s][(co, s)]                                (a shifted sum, done through LDS)
+// i.e. 140 MFMAs per 64 output pixels instead of 392, and one fragment read per 2 MFMAs.  The weight fragments (28 per
+// lane) live in registers for the whole block.  One block = 8 output rows x 64 columns, one wave per row; the 14 x 70
+// pixel input halo (128 B per pixel) is DMA'd once, REFLECT / zero padding resolved in the per-lane source address.
+// -------------------------------------------------------------------------------------------------
+#define N7_TH 8
+#define N7_TW 64
+#define N7_PITCH 72                                     // halo row pitch in pixels (70 used; 9 DMAs of 8)
+#define N7_ROWS (N7_TH + 6)
+#define N7_LDS (N7_ROWS * N7_PITCH * 128 + 2048)
+#define N7_ZP 68                                        // floats per (co, s) row of the shifted-sum buffer
+
+struct N7Args {
+    const char* src;     // (N,H,W,64) bf16
+    const char* wmat;    // [dest channel][49 taps][64] bf16 (w_fwd of the head / w_dgrad of the stem)
+    const float* bias;   // per dest channel or nullptr
+    void* dst;           // bf16 (N,Ho,Wo,8)  or  f32 (N,Ho,Wo,4) when dst_f32
+    int N, H, W, Ho, Wo, pt, pl, K, reflect, flip, act, dst_f32;
+    float leak;
+};
+
+__global__ __launch_bounds__(512) void conv7_narrow_out_kernel(N7Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* const lH = (lds_char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tilesW = (a.Wo + N7_TW - 1) / N7_TW, tilesH = (a.Ho + N7_TH - 1) / N7_TH;
+    const int ntiles = a.N * tilesH * tilesW;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    const int frow = lane & 15, fq = lane >> 4;
+    // ---- weight fragments into registers, once per (persistent) block: 28 x 16 B per lane.  B operand: lane supplies
+    // k = 8*(lane/16).., column n = nt*16 + lane%16
+    u32x4 wr[7][2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int nn = nt * 16 + frow, co = nn >> 3, sc = nn & 7;
+        const bool ok = co < a.K && co < 3 && sc < 7;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const int tap = a.flip ? (6 - r) * 7 + (6 - sc) : r * 7 + sc;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                wr[r][kk][nt] = ok ? ld16(a.wmat + (((size_t)co * 49 + tap) * 64 + kk * 32 + fq * 8) * 2) : zero16();
+        }
+    }
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int b = tile;
+    const int tw = b % tilesW; b /= tilesW;
+    const int th = b % tilesH;
+    const int n = b / tilesH;
+    const int y0 = th * N7_TH, x0 = tw * N7_TW;
+    __syncthreads();                                    // the previous tile's shifted-sum buffer (in the halo region) is done
+
+    // ---- halo DMA: 14 rows x 9 instructions of 8 pixels; instruction id = row * 9 + i, dealt round-robin to the waves
+    {
+        const int hsub = lane >> 3, hpos = lane & 7;
+        for (int id = wave; id < N7_ROWS * 9; id += 8) {
+            const int hy = id / 9, hx = (id - hy * 9) * 8 + hsub;
+            int yi = y0 - a.pt + hy, xi = x0 - a.pl + hx;
+            bool ok = hx < N7_TW + 6;
+            if (a.reflect) {
+                yi = yi < 0 ? -yi : (yi >= a.H ? 2 * (a.H - 1) - yi : yi);
+                xi = xi < 0 ? -xi : (xi >= a.W ? 2 * (a.W - 1) - xi : xi);
+                ok = ok && (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W;   // (tiles past the image edge)
+            } else ok = ok && (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W;
+            const int hp = hy * N7_PITCH + hx;
+            const int key = (hp >> 1) & 7;
+            const char* src = ok ? a.src + ((((size_t)n * a.H + yi) * a.W + xi) * 64) * 2 + ((hpos ^ key) << 4) : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lH + (hy * N7_PITCH + (id - hy * 9) * 8) * 128), 16, 0, 0);
+        }
+    }
+    f32x4 acc[5][2];
+#pragma unroll
+    for (int qf = 0; qf < 5; ++qf)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[qf][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- D[q][(co,s)] for this wave's output row: A operand = halo pixels (lane: pixel frow, chunk fq), B = weights
+    const char* sH = smem;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const int hrow = wave + r;
+        const int key = ((hrow * 4) + (frow >> 1)) & 7;             // (hp >> 1) & 7 with hp = hrow*72 + qf*16 + frow
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const char* base = sH + ((size_t)(hrow * N7_PITCH + frow)) * 128 + (((kk * 4 + fq) ^ key) << 4);
+#pragma unroll
+            for (int qf = 0; qf < 5; ++qf) {
+                const u32x4 px = ld16(base + qf * 16 * 128);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[qf][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, px), __builtin_bit_cast(bf16x8, wr[r][kk][nt]),
+                                                                          acc[qf][nt], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                                 // every wave is done with the halo: reuse it for Z
+
+    // ---- shifted sum: Z[(co,s)][p] = D[p + s][(co,s)], then out[p][co] = sum_s Z[(co,s)][p] (fixed order)
+    float* Z = reinterpret_cast<float*>(smem) + (size_t)wave * (21 * N7_ZP);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int nn = nt * 16 + frow, co = nn >> 3, sc = nn & 7;
+        if (co < 3 && sc < 7) {
+#pragma unroll
+            for (int qf = 0; qf < 5; ++qf)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int pcol = qf * 16 + fq * 4 + e - sc;
+                    if ((unsigned)pcol < (unsigned)N7_TW) Z[(co * 7 + sc) * N7_ZP + pcol] = acc[qf][nt][e];
+                }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int y = y0 + wave, x = x0 + lane;
+    float o[3];
+#pragma unroll
+    for (int co = 0; co < 3; ++co) {
+        float v = 0.f;
+#pragma unroll
+        for (int sc = 0; sc < 7; ++sc) v += Z[(co * 7 + sc) * N7_ZP + lane];
+        o[co] = (co < a.K) ? act_apply(v + (a.bias ? a.bias[co] : 0.f), a.act, a.leak) : 0.f;
+    }
+    if (y < a.Ho && x < a.Wo) {
+        const size_t pix = ((size_t)n * a.Ho + y) * a.Wo + x;
+        if (a.dst_f32) {
+            reinterpret_cast<f32x4*>(a.dst)[pix] = (f32x4){o[0], o[1], o[2], 0.f};
+        } else {
+            u32x4 pk = zero16();
+            const bf16 b0 = (bf16)o[0], b1 = (bf16)o[1], b2 = (bf16)o[2];
+            pk[0] = (uint32_t)__builtin_bit_cast(uint16_t, b0) | ((uint32_t)__builtin_bit_cast(uint16_t, b1) << 16);
+            pk[1] = (uint32_t)__builtin_bit_cast(uint16_t, b2);
+            st16(reinterpret_cast<char*>(a.dst) + pix * 16, pk);
+        }
+    }
+  }
+}
+
+// MirrorPadGrad for REFLECT pad 3 (tf.pad backward in front of the stem, module.py:230): dxp is the data gradient on the
+// PADDED grid (N, H+6, W+6, 4) f32; every image pixel sums its (up to 2 x 2) mirror pre-images in fixed order and is
+// rounded to bf16 once.
+__global__ __launch_bounds__(256) void pad3_fold_kernel(const f32x4* dxp, char* dx, int N, int H, int W) {
+    const int64_t total = (int64_t)N * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        const int64_t t = i / W;
+        const int h = (int)(t % H), n = (int)(t / H);
+        int jh[3], jw[3];
+        const int nh = reflect_preimages(h, H, 3, jh), nw = reflect_preimages(w, W, 3, jw);
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        for (int ih = 0; ih < nh; ++ih)
+            for (int iw = 0; iw < nw; ++iw) {
+                const f32x4 d = dxp[((size_t)n * (H + 6) + jh[ih]) * (W + 6) + jw[iw]];
+                v0 += d[0]; v1 += d[1]; v2 += d[2];
+            }
+        u32x4 pk = zero16();
+        const bf16 b0 = (bf16)v0, b1 = (bf16)v1, b2 = (bf16)v2;
+        pk[0] = (uint32_t)__builtin_bit_cast(uint16_t, b0) | ((uint32_t)__builtin_bit_cast(uint16_t, b1) << 16);
+        pk[1] = (uint32_t)__builtin_bit_cast(uint16_t, b2);
+        st16(dx + (size_t)i * 16, pk);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Weight gradient of the two 7x7 layers with a 3-channel side (bf16): the head (64 -> 3, module.py:262-264) and the
+// stem (3 -> 64, module.py:230-232).  Both are
+//     G[r][s][c][j] = sum_{n, py, px} A~[n][py + r - pa][px + s - pa][c] * B[n][py][px][j],     c < 64, j < 3
+// with A the 64-channel tensor (head: the layer input, REFLECT padded; stem: dy, zero padded by 6 -- the sum then runs
+// over the PADDED grid, B = the explicitly reflect-padded input, and taps come out mirrored) and B the 3-channel one.
+// conv_halo_wgrad_kernel gives every tap its own MFMAs with 13 of 16 columns empty (196 per 32 pixels, two LDS reads
+// each).  Here the GEMM N dimension carries (j, tap column s) = 3 x 7 -> 32 and each wave owns ONE tap row r:
+//     D_r[c][(j,s)] += sum_q A~[py + r][q][c] * Bs[py][q][(j,s)],      Bs[py][q][(j,s)] = B[py][q - s][j]
+// (q = padded column inside a 58-pixel strip: 64 values = two k-steps), 8 MFMAs per 32 pixels and wave, 12 LDS reads.
+// Bs -- an im2col of the 3-channel tensor along the row, 64 B per pixel -- is built in LDS by the eighth wave while
+// waves 0..6 multiply.  A block walks down a strip 4 rows at a time: the 4 new A rows are DMA'd into a 14-row ring
+// while the other 10 are in use.  Both operands are read with the transposing ds_read_b64_tr_b16 (pixels are the
+// reduction index).  One f32 slab [7][64][32] per block; wgrad7_reduce_kernel sums them in fixed order.
+// -------------------------------------------------------------------------------------------------
+#define W7_TW 58                                        // strip width in pixels of B's grid (58 + 6 = 64 = two k-steps)
+#define W7_AROW (64 * 128)                              // bytes per A row (64 pixels x 64 channels)
+#define W7_BSROW (64 * 64)                              // bytes per Bs row (64 pixels x 32 columns)
+// RS rows per step; A rows are DMA'd PD steps ahead (they come from HBM: ~2 us under load, a step is < 1 us) into a
+// ring of RS + 6 + PD*RS rows; raw B rows three steps ahead into a ring of 4 steps; Bs double-buffered.
+template <int RS, int PD> struct W7Cfg {
+    static constexpr int RING = RS + 6 + PD * RS;
+    static constexpr int OFF_BS = RING * W7_AROW;
+    static constexpr int OFF_BRAW = OFF_BS + 2 * RS * W7_BSROW;
+    static constexpr int LDS = OFF_BRAW + 4 * RS * 512 + 1024;
+    static constexpr int B_PER_STEP = RS * 2;           // raw-B DMA instructions per step (wave 7)
+    static constexpr int NISS = 6;                      // waves 0..5 issue the main loop's A-row DMAs (wave 7 has the B side)
+    static constexpr int A_PER_WAVE = RS * 8 / NISS;    // RS rows x 8 instructions over the issuer waves
+    static_assert(RS * 8 % NISS == 0, "issuer waves must carry equal DMA counts (the vmcnt bookkeeping relies on it)");
+};
+
+struct W7Args {
+    const char* A;       // (N,HA,WA,64) bf16
+    const char* B;       // (N,HB,WB,8) bf16 -- the summation grid
+    float* slabs;        // [blocks][7][64][32] f32
+    int N, HA, WA, HB, WB, pa, reflectA, nstrips, nseg, rows_per_seg;
+    int ablate;          // lab build only (SGG_ABLATE): 1 no fragment reads / MFMAs, 2 no Bs build, 3 no A-row DMA in the loop
+};
+
+template <int N> __device__ inline void w7_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int RS, int PD>
+__global__ __launch_bounds__(512) void wgrad7_kernel(W7Args a) {
+    using Cfg = W7Cfg<RS, PD>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* const lds = (lds_char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    int b = blockIdx.x;
+    const int seg = b % a.nseg; b /= a.nseg;
+    const int strip = b % a.nstrips;
+    const int n = b / a.nstrips;
+    const int yb = seg * a.rows_per_seg;
+    const int ye = yb + a.rows_per_seg < a.HB ? yb + a.rows_per_seg : a.HB;
+    const int x0 = strip * W7_TW;
+    const int nsteps = (ye - yb + RS - 1) / RS;
+
+    // ---- A rows: ring row k (k = 0 .. rows + 5) is image row yb + k - pa; 8 DMA instructions of 8 pixels per row.
+    // Rows k0 .. k0+nrows-1; instruction ids are dealt round-robin to the issuing waves.  Rows past the image read the zero page.
+    const int hsub = lane >> 3, hpos = lane & 7;
+    auto load_a_rows = [&](int k0, int nrows, int vw, int nw) {          // this wave acts as issuer vw of nw
+        for (int id = vw; id < nrows * 8; id += nw) {
+            const int k = k0 + (id >> 3), i = id & 7;
+            const int q = i * 8 + hsub;
+            int yi = yb + k - a.pa, xi = x0 - a.pa + q;
+            if (a.reflectA) {
+                yi = yi < 0 ? -yi : (yi >= a.HA ? 2 * (a.HA - 1) - yi : yi);
+                xi = xi < 0 ? -xi : (xi >= a.WA ? 2 * (a.WA - 1) - xi : xi);
+            }
+            const bool ok = (unsigned)yi < (unsigned)a.HA && (unsigned)xi < (unsigned)a.WA;
+            const int key = ((q >> 1) & 1) | (((q >> 3) & 1) << 1);           // keyed on pixel bits 1 and 3: the transposed reads are conflict-free
+            const char* src = ok ? a.A + ((((size_t)n * a.HA + yi) * a.WA + xi) * 64) * 2 + ((hpos ^ (key << 1)) << 4) : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + (k % Cfg::RING) * W7_AROW + i * 1024), 16, 0, 0);
+        }
+    };
+    // ---- B rows of a step (wave 7): raw row DMA, then the im2col Bs[q][(j,s)] = B[q - s][j]
+    auto load_b_raw = [&](int step) {                    // one lane = one pixel; a 4-byte wave-instruction moves 64 x 4 B:
+        for (int i = 0; i < RS; ++i) {                   // dword 0 = channels (0,1), dword 1 = (2,3)
+            const int py = yb + step * RS + i, px = x0 + lane;
+            const bool ok = py < ye && lane < W7_TW && px < a.WB;
+            const char* src = ok ? a.B + (((size_t)n * a.HB + py) * a.WB + px) * 16 : zero;
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + part * 4),
+                                                 (__attribute__((address_space(3))) void*)(lds + Cfg::OFF_BRAW + ((step & 3) * RS + i) * 512 + part * 256), 4, 0, 0);
+        }
+    };
+    auto build_bs = [&](int step) {
+        char* bs = smem + Cfg::OFF_BS + (step & 1) * (RS * W7_BSROW);
+        const int q = lane;
+        const int bsw = ((q >> 3) & 1) << 1;                                   // chunk swizzle of the Bs rows
+        for (int i = 0; i < RS; ++i) {
+            const char* raw = smem + Cfg::OFF_BRAW + ((step & 3) * RS + i) * 512;   // [part 0..1][pixel] dwords
+            uint32_t lo[7], hi[7];                                             // pixel q - s: channels (0,1) and (2,3)
+#pragma unroll
+            for (int sc = 0; sc < 7; ++sc) {
+                const int idx = q - sc;
+                const bool ok = idx >= 0;
+                lo[sc] = ok ? *reinterpret_cast<const uint32_t*>(raw + 4 * idx) : 0u;
+                hi[sc] = ok ? *reinterpret_cast<const uint32_t*>(raw + 256 + 4 * idx) : 0u;
+            }
+            // columns n = j*8 + s: 16-byte chunk j holds s = 0..6 (+ a zero) for channel j; chunk 3 is zero
+            u32x4 ch[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                uint32_t e[8];
+#pragma unroll
+                for (int sc = 0; sc < 7; ++sc) {
+                    const uint32_t w = j < 2 ? lo[sc] : hi[sc];
+                    e[sc] = (j == 1) ? (w >> 16) : (w & 0xffffu);
+                }
+                e[7] = 0u;
+                ch[j] = (u32x4){e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+            }
+            char* row = bs + i * W7_BSROW + q * 64;
+            st16(row + ((0 ^ bsw) << 4), ch[0]);
+            st16(row + ((1 ^ bsw) << 4), ch[1]);
+            st16(row + ((2 ^ bsw) << 4), ch[2]);
+            st16(row + ((3 ^ bsw) << 4), zero16());
+        }
+    };
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) acc[it][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // prologue (all 8 waves issue, everything is drained): A rows of steps 0 .. PD-1, raw B of steps 0 and 1, Bs of step 0
+    if (wave == 7) load_b_raw(0);
+    load_a_rows(0, RS + 6 + (PD - 1) * RS, wave, 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave == 7) {
+        build_bs(0);
+        load_b_raw(1);
+        load_b_raw(2);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // Transposed fragment reads: lane 4qq+pp of 16-lane group g supplies row (pixel) 8g+qq [+4 for the upper half], columns
+    // 4pp..4pp+3 of the 16-column tile.  Everything lane-dependent is folded into six LDS byte addresses computed once
+    // (the swizzle keys depend only on pixel bits 1 and 3 = qq bit 1 and g bit 0); a read is then base + scalar + immediate.
+    const int g = lane >> 4, u = lane & 15, qq = u >> 2, pp = u & 3;
+    const uint32_t lb = (uint32_t)(uintptr_t)lds;
+    const int keyA = ((qq >> 1) & 1) | ((g & 1) << 1);
+    uint32_t offA[4], offB[2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) offA[it] = lb + (8 * g + qq) * 128 + ((((it ^ keyA) << 1) | (pp >> 1)) << 4) + (pp & 1) * 8;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) offB[jt] = lb + Cfg::OFF_BS + (8 * g + qq) * 64 + ((((jt * 2) | (pp >> 1)) ^ ((g & 1) << 1)) << 4) + (pp & 1) * 8;
+    auto tr = [](uint32_t addr) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(uintptr_t)addr); };
+    for (int t = 0; t < nsteps; ++t) {
+        // rows of step t + PD into the slots step t - 1 released, by waves 0..5 (always issued: rows past the segment are
+        // harmless and keep every issuer's count of outstanding DMAs per step constant)
+        if (wave < Cfg::NISS && SGG_ABLATE_OF(a) != 3) load_a_rows(RS + 6 + (t + PD - 1) * RS, RS, wave, Cfg::NISS);
+        if (wave < 7 && SGG_ABLATE_OF(a) == 1) {
+        } else if (wave < 7) {
+            const int r = wave;
+            // RS x 2 batches of (2 B + 4 A fragments -> 8 MFMAs); the fragments of batch b+1 are requested before the MFMAs
+            // of batch b are issued (a batch's reads would otherwise sit exposed: ~200 cycles of LDS latency per 128 of MFMA)
+            bf16x4 fbq[2][2][2], faq[2][4][2];            // [buffer][tile][lo/hi]
+            auto request = [&](int bi, int buf) {
+                const int i = bi >> 1, ks = bi & 1;
+                const uint32_t abase = (uint32_t)((t * RS + i + r) % Cfg::RING) * W7_AROW + ks * 32 * 128;
+                const uint32_t bbase = (uint32_t)((t & 1) * RS + i) * W7_BSROW + ks * 32 * 64;
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) { fbq[buf][jt][0] = tr(offB[jt] + bbase); fbq[buf][jt][1] = tr(offB[jt] + bbase + 4 * 64); }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) { faq[buf][it][0] = tr(offA[it] + abase); faq[buf][it][1] = tr(offA[it] + abase + 4 * 128); }
+            };
+            request(0, 0);
+#pragma unroll
+            for (int bi = 0; bi < RS * 2; ++bi) {
+                const int buf = bi & 1;
+                if (bi + 1 < RS * 2) request(bi + 1, buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8 fb[2];
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) {
+                    const bf16x4 lo = fbq[buf][jt][0], hi = fbq[buf][jt][1];
+                    fb[jt] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const bf16x4 lo = faq[buf][it][0], hi = faq[buf][it][1];
+                    const bf16x8 fa = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                    for (int jt = 0; jt < 2; ++jt) acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[jt], acc[it][jt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the rows of step t+1 (issued PD-1 steps ago) have landed; the later steps' may still be in flight
+            if (wave < Cfg::NISS) w7_wait_vm<Cfg::A_PER_WAVE * (PD - 1)>();
+        } else {
+            // wave 7: raw B of step t+1 (issued TWO steps ago; only its own B DMAs are in its queue, step t+2's may still
+            // fly) -> Bs(t+1) while the others multiply; then the raw B of step t+3 goes out.  (With the raw rows requested
+            // only one step ahead this wave sat out a full HBM latency per step, and the block with it.)
+            w7_wait_vm<Cfg::B_PER_STEP>();
+            if (SGG_ABLATE_OF(a) != 2) build_bs(t + 1);
+            load_b_raw(t + 3);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing may still be writing LDS when the block retires
+
+    // D_r[row = it*16 + 4g + e -> channel c][col = jt*16 + u -> (j,s)]
+    if (wave < 7) {
+        float* slab = a.slabs + ((size_t)blockIdx.x * 7 + wave) * 64 * 32;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) slab[(it * 16 + 4 * g + e) * 32 + jt * 16 + u] = acc[it][jt][e];
+    }
+}
+
+// dw[...] (+)= sum over blocks of slab[b][r][c][j*8 + s], in fixed order.  mode 0 (head): dw is HWIO (7,7,64,Kr):
+// dw[r][s][c][j].  mode 1 (stem): dw is (7,7,Cr,64) and the taps come out mirrored: dw[6-r][6-s][j][c].
+__global__ __launch_bounds__(1024) void wgrad7_reduce_kernel(const float* slabs, int nblocks, float* dw, int mode, int nj, int accumulate) {
+    __shared__ float red[32][32];
+    const int o = threadIdx.x & 31, part = threadIdx.x >> 5;     // 32 outputs x 32 slab lanes
+    const int idx = blockIdx.x * 32 + o;                 // (r, c, col) with col = j*8 + s in 0..31
+    const int col = idx & 31, c = (idx >> 5) & 63, r = idx >> 11;
+    float v = 0.f;
+    for (int b0 = part; b0 < nblocks; b0 += 32 * 4) {    // four independent loads in flight, added in slab order
+        float x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int b = b0 + 32 * k;
+            x[k] = b < nblocks ? slabs[(size_t)b * (7 * 64 * 32) + idx] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v += x[k];
+    }
+    red[part][o] = v;
+    __syncthreads();
+    if (part == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int p = 0; p < 32; ++p) t += red[p][o];
+        const int j = col >> 3, sc = col & 7;
+        if (j < nj && sc < 7) {
+            float* d = mode == 0 ? dw + ((size_t)(r * 7 + sc) * 64 + c) * nj + j
+                                 : dw + ((size_t)((6 - r) * 7 + (6 - sc)) * nj + j) * 64 + c;
+            *d = accumulate ? *d + t : t;
+        }
+    }
+}
+
+// explicit REFLECT pad 3 of an 8-channel bf16 tensor (the stem's input, as wgrad7_kernel's B operand): (N,H,W,8) -> (N,H+6,W+6,8)
+__global__ __launch_bounds__(256) void reflect_pad3_kernel(const char* x, char* xp, int N, int H, int W) {
+    const int Hp = H + 6, Wp = W + 6;
+    const int64_t total = (int64_t)N * Hp * Wp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int wp = (int)(i % Wp);
+        const int64_t t = i / Wp;
+        const int hp = (int)(t % Hp), n = (int)(t / Hp);
+        int h = hp - 3, w = wp - 3;
+        h = h < 0 ? -h : (h >= H ? 2 * (H - 1) - h : h);
+        w = w < 0 ? -w : (w >= W ? 2 * (W - 1) - w : w);
+        st16(xp + (size_t)i * 16, ld16(x + (((size_t)n * H + h) * W + w) * 16));
+    }
+}
+
+static bool w7_head_ok(const sgg_conv_desc* d) {        // 64 -> <= 3 (stored 8), 7x7, pad 3
+    return sgg_config().n7 && d->dtype == SGG_BF16 && d->R == 7 && d->S == 7 && d->stride == 1 && d->C == 64 && d->K == 8 &&
+           d->Ho == d->H && d->Wo == d->W && d->pad_t == 3 && d->pad_l == 3 && d->H >= 8 && d->W >= 8;
+}
+static bool w7_stem_ok(const sgg_conv_desc* d) {        // <= 3 (stored 8) -> 64, 7x7, REFLECT 3
+    return sgg_config().n7 && d->dtype == SGG_BF16 && d->R == 7 && d->S == 7 && d->stride == 1 && d->C == 8 && d->K == 64 &&
+           d->Ho == d->H && d->Wo == d->W && d->pad_t == 3 && d->pad_l == 3 && d->pad_mode == SGG_PAD_REFLECT && d->H >= 8 && d->W >= 8;
+}
+#ifndef W7_RSTEP
+#define W7_RSTEP 3
+#define W7_PDIST 2
+#endif
+struct W7Plan { int HB, WB, nstrips, nseg, rows_per_seg, blocks; size_t slab_bytes, xpad_bytes; };
+static W7Plan w7_plan(const sgg_conv_desc* d, bool stem) {
+    W7Plan p;
+    p.HB = d->H + (stem ? 6 : 0); p.WB = d->W + (stem ? 6 : 0);
+    p.nstrips = (p.WB + W7_TW - 1) / W7_TW;
+    int nseg = 512 / (d->N * p.nstrips);                 // ~2 blocks per CU (one resident at a time: 150 KB of LDS)
+    if (nseg < 1) nseg = 1;
+    int rps = (p.HB + nseg - 1) / nseg;
+    rps = (rps + W7_RSTEP - 1) / W7_RSTEP * W7_RSTEP;
+    if (rps < 8) rps = 8;
+    p.rows_per_seg = rps;
+    p.nseg = (p.HB + rps - 1) / rps;
+    p.blocks = d->N * p.nstrips * p.nseg;
+    p.slab_bytes = (size_t)p.blocks * 7 * 64 * 32 * sizeof(float);
+    p.xpad_bytes = stem ? align_up((size_t)d->N * p.HB * p.WB * 16, 256) : 0;
+    return p;
+}
+static int run_w7(const sgg_conv_desc* d, bool stem, const void* x, const void* dy, float* dw, int Cr, int Kr, int accumulate,
+                  void* ws, size_t ws_bytes, hipStream_t s) {
+    const W7Plan p = w7_plan(d, stem);
+    if (!ws || ws_bytes < p.slab_bytes + p.xpad_bytes) return SGG_EWORKSPACE;
+    if ((stem ? Cr : Kr) > 3) return SGG_EUNSUPPORTED;
+    W7Args a;
+    a.slabs = (float*)ws;
+    a.N = d->N; a.HB = p.HB; a.WB = p.WB; a.nstrips = p.nstrips; a.nseg = p.nseg; a.rows_per_seg = p.rows_per_seg;
+    a.HA = d->H; a.WA = d->W; a.ablate = sgg_config().ablate;
+    if (stem) {
+        char* xpad = (char*)ws + p.slab_bytes;
+        const int64_t total = (int64_t)d->N * p.HB * p.WB;
+        int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(reflect_pad3_kernel, dim3(blocks), dim3(256), 0, s, (const char*)x, xpad, d->N, d->H, d->W);
+        a.A = (const char*)dy; a.B = xpad; a.pa = 6; a.reflectA = 0;
+    } else {
+        a.A = (const char*)x; a.B = (const char*)dy; a.pa = 3; a.reflectA = d->pad_mode == SGG_PAD_REFLECT;
+    }
+    auto kern = wgrad7_kernel<W7_RSTEP, W7_PDIST>;
+    constexpr int lds = W7Cfg<W7_RSTEP, W7_PDIST>::LDS;
+    static_assert(lds <= 160 * 1024, "wgrad7 LDS budget");
+    SGG_LDS_ATTR(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.blocks), dim3(512), lds, s, a);
+    int rc = sgg_check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(wgrad7_reduce_kernel, dim3(7 * 64 * 32 / 32), dim3(1024), 0, s, (const float*)ws, p.blocks, dw, stem ? 1 : 0, stem ? Cr : Kr, accumulate);
+    return sgg_check_launch();
+}
+
+// head forward: 7x7 stride 1, 64 -> <= 3 channels (stored in 8), bf16, same-size output
+static bool n7_fwd_ok(const sgg_conv_desc* d) {
+    return sgg_config().n7 && d->dtype == SGG_BF16 && d->R == 7 && d->S == 7 && d->stride == 1 && d->C == 64 && d->K == 8 &&
+           d->Ho == d->H && d->Wo == d->W && d->pad_t == 3 && d->pad_l == 3 && d->H >= 8 && d->W >= 8;
+}
+// stem data gradient: conv 7x7 REFLECT-3, <= 3 -> 64 channels; as a conv over dy it is the head's shape with mirrored taps
+static bool n7_dgrad_ok(const sgg_conv_desc* d) {
+    return sgg_config().n7 && d->dtype == SGG_BF16 && d->R == 7 && d->S == 7 && d->stride == 1 && d->K == 64 && d->C == 8 &&
+           d->Ho == d->H && d->Wo == d->W && d->pad_t == 3 && d->pad_l == 3 && d->pad_mode == SGG_PAD_REFLECT && d->H >= 8 && d->W >= 8;
+}
+static size_t n7_dgrad_ws(const sgg_conv_desc* d) { return (size_t)d->N * (d->H + 6) * (d->W + 6) * 16; }
+
+static int launch_n7(const N7Args& a, hipStream_t s) {
+    SGG_LDS_ATTR(conv7_narrow_out_kernel, N7_LDS);
+    const int64_t tiles = (int64_t)a.N * ((a.Ho + N7_TH - 1) / N7_TH) * ((a.Wo + N7_TW - 1) / N7_TW);
+    const int64_t per = (tiles + 255) / 256;            // persistent blocks, one per CU, equal tile counts
+    const int64_t blocks = (tiles + per - 1) / per;
+    hipLaunchKernelGGL(conv7_narrow_out_kernel, dim3((unsigned)blocks), dim3(512), N7_LDS, s, a);
+    return sgg_check_launch();
 }
 
 static bool halo_fwd_ok(const sgg_conv_desc* d) {
@@ -2873,6 +3397,10 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S; a.stride = d->stride;
     a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.reflect = d->pad_mode == SGG_PAD_REFLECT;
     a.P = d->N * d->Ho * d->Wo;
+    if constexpr (sizeof(T) == 2) {                     // the two 7x7 layers with a 3-channel side
+        if (use_glds() && w7_head_ok(d)) return run_w7(d, false, x, dy, dw, Cr, Kr, accumulate, ws, ws_bytes, s);
+        if (use_glds() && w7_stem_ok(d)) return run_w7(d, true, x, dy, dw, Cr, Kr, accumulate, ws, ws_bytes, s);
+    }
     if (halo_wgrad_ok(d)) {
         const int nb = halo_wgrad_blocks(d), ntiles = d->N * (d->H / HALO_TH) * (d->W / HALO_TW);
         size_t need = (size_t)nb * d->R * d->S * d->C * d->K * sizeof(float);
@@ -2997,6 +3525,13 @@ int sgg_conv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w, const f
     ConvArgs a = make_args(d, x, w, bias, y, act, leak);
     if (halo_narrow_in_ok(d, d->C, d->K))               // narrow input (stem): halo + whole weight matrix resident in LDS
         return d->dtype == SGG_BF16 ? launch_halo_narrow_in<bf16>(d, a, 0, (hipStream_t)stream) : launch_halo_narrow_in<float>(d, a, 0, (hipStream_t)stream);
+    if (use_glds() && n7_fwd_ok(d)) {                    // the 7x7 head: (channel, tap column) in the GEMM N dimension
+        N7Args q;
+        q.src = (const char*)x; q.wmat = (const char*)w; q.bias = bias; q.dst = y;
+        q.N = d->N; q.H = d->H; q.W = d->W; q.Ho = d->Ho; q.Wo = d->Wo; q.pt = 3; q.pl = 3; q.K = 3;
+        q.reflect = d->pad_mode == SGG_PAD_REFLECT; q.flip = 0; q.act = act; q.leak = leak; q.dst_f32 = 0;
+        return launch_n7(q, (hipStream_t)stream);
+    }
     if (use_glds() && halo_fwd_ok(d))                   // narrow output at full resolution: input halo resident in LDS
         return d->dtype == SGG_BF16 ? launch_halo_fwd<bf16>(d, a, (hipStream_t)stream) : launch_halo_fwd<float>(d, a, (hipStream_t)stream);
     return d->dtype == SGG_BF16 ? run_gemm<bf16, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream)
@@ -3028,6 +3563,7 @@ static size_t fold_bytes(const sgg_conv_desc* d) {
 
 size_t sgg_conv2d_bwd_data_workspace(const sgg_conv_desc* d) {
     if (!desc_ok(d)) return 0;
+    if (use_glds() && n7_dgrad_ok(d)) return n7_dgrad_ws(d);
     return fold_bytes(d) + plan_gemm(d, MODE_DGRAD).ws_bytes;
 }
 
@@ -3047,6 +3583,21 @@ static int conv2d_bwd_data_impl(const sgg_conv_desc* d, const void* dy, const vo
         if (rc0 || !a.reflect) return rc0;
         // REFLECT: add the mirrored (MirrorPadGrad) terms of the border pixels with the small register-path launch
         return d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_BORDER>(a, (hipStream_t)stream) : launch_gemm<float, MODE_BORDER>(a, (hipStream_t)stream);
+    }
+    if (!addend && !nb && use_glds() && n7_dgrad_ok(d)) {
+        // the stem: data gradient on the PADDED grid (a zero-padded "full" correlation of dy with the mirrored taps, f32),
+        // then MirrorPadGrad as a fold of the 3-pixel frame onto the image -- one rounding, no separate border GEMM
+        if (!ws || ws_bytes < n7_dgrad_ws(d)) return SGG_EWORKSPACE;
+        N7Args q;
+        q.src = (const char*)dy; q.wmat = (const char*)w; q.bias = nullptr; q.dst = ws;
+        q.N = d->N; q.H = d->H; q.W = d->W; q.Ho = d->H + 6; q.Wo = d->W + 6; q.pt = 6; q.pl = 6; q.K = 3;
+        q.reflect = 0; q.flip = 1; q.act = SGG_ACT_NONE; q.leak = 0.f; q.dst_f32 = 1;
+        int rc0 = launch_n7(q, (hipStream_t)stream);
+        if (rc0) return rc0;
+        const int64_t total = (int64_t)d->N * d->H * d->W;
+        int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(pad3_fold_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)ws, (char*)dx, d->N, d->H, d->W);
+        return sgg_check_launch();
     }
     if (!addend && halo_dgrad_narrow_ok(d)) {
         ConvArgs h = a;                                  // the same computation written as a forward conv over dy
@@ -3104,6 +3655,10 @@ int sgg_conv2d_bwd_data_stats(const sgg_conv_desc* d, const void* dy, const void
 
 size_t sgg_conv2d_bwd_weight_workspace(const sgg_conv_desc* d) {
     if (!desc_ok(d)) return 0;
+    if (use_glds() && (w7_head_ok(d) || w7_stem_ok(d))) {
+        const W7Plan p = w7_plan(d, w7_stem_ok(d));
+        return p.slab_bytes + p.xpad_bytes;
+    }
     return (size_t)wgrad_splits(d) * d->R * d->S * d->C * d->K * sizeof(float);
 }
 

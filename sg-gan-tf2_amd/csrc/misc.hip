@@ -307,17 +307,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* th, const float* g, fl
 }
 
 // Same update with the step number read from a device-resident counter (Keras keeps `optimizer.iterations` as a variable
-// too): t = *iterations + 1.  The host never touches t, so the launch can sit inside a captured HIP graph and be
-// replayed.  lr_t is evaluated in double by one lane per block (same formula as the host path of sgg_adam).
-__global__ __launch_bounds__(256) void adam_iter_kernel(float* th, const float* g, float* m, float* v, int64_t n, const int64_t* iterations,
-                                                        float lr, float b1, float b2, float eps, float gs) {
-    __shared__ float lr_t_s;
-    if (threadIdx.x == 0) {
-        const double t = (double)(*iterations + 1);
-        lr_t_s = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
-    }
-    __syncthreads();
-    const float lr_t = lr_t_s;
+// too).  `state` is int64[2]: [0] = iterations, [1] = scratch (the bits of lr_t for the step being applied).  A 1-thread
+// launch evaluates lr_t in double from t = iterations + 1 (same formula as the host path of sgg_adam) and bumps the
+// counter; the update kernel reads the float.  The host never touches t, so the pair of launches can sit inside a captured
+// HIP graph and be replayed.  (Evaluating pow() in every block of the update kernel cost +18 us per launch.)
+__global__ void adam_prep_kernel(int64_t* state, float lr, float b1, float b2) {
+    const double t = (double)(state[0] + 1);
+    const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+    state[0] += 1;
+    reinterpret_cast<float*>(state + 1)[0] = lr_t;
+}
+__global__ __launch_bounds__(256) void adam_iter_kernel(float* th, const float* g, float* m, float* v, int64_t n, const int64_t* state,
+                                                        float b1, float b2, float eps, float gs) {
+    const float lr_t = reinterpret_cast<const float*>(state + 1)[0];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float gi = g[i] * gs;
         float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -326,7 +328,6 @@ __global__ __launch_bounds__(256) void adam_iter_kernel(float* th, const float* 
         th[i] = th[i] - lr_t * mi / (sqrtf(vi) + eps);
     }
 }
-__global__ void counter_inc_kernel(int64_t* c) { *c += 1; }     // its own launch: every block of the update has read t by now
 
 // ---------------------------------------------------------------- colour -> class index (integer, bit exact)
 // segment_class.py:63-66: 21 colours -> {1..7}; default 0.  Keys are 24-bit (R<<16|G<<8|B).
@@ -550,16 +551,14 @@ int sgg_adam(float* theta, const float* g, float* m, float* v, int64_t n, int t,
     return sgg_check_launch();
 }
 
-int sgg_adam_iter(float* theta, const float* g, float* m, float* v, int64_t n, int64_t* iterations, float lr, float beta1, float beta2,
+int sgg_adam_iter(float* theta, const float* g, float* m, float* v, int64_t n, int64_t* state, float lr, float beta1, float beta2,
                   float eps, float grad_scale, void* stream) {
-    if (!theta || !g || !m || !v || !iterations || n < 0) return SGG_EINVAL;
-    if (n > 0) {
-        hipLaunchKernelGGL(adam_iter_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, n, (const int64_t*)iterations,
-                           lr, beta1, beta2, eps, grad_scale);
-        int rc = sgg_check_launch();
-        if (rc) return rc;
-    }
-    hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, iterations);
+    if (!theta || !g || !m || !v || !state || n < 0) return SGG_EINVAL;
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, lr, beta1, beta2);
+    int rc = sgg_check_launch();
+    if (rc || n == 0) return rc;
+    hipLaunchKernelGGL(adam_iter_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, n, (const int64_t*)state,
+                       beta1, beta2, eps, grad_scale);
     return sgg_check_launch();
 }
 

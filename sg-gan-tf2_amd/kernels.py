@@ -415,11 +415,11 @@ def adam(theta, g, m, v, t, lr=1e-3, beta1=0.5, beta2=0.999, eps=1e-7, grad_scal
     A.check(A.lib().sgg_adam(_p(theta), _p(g), _p(m), _p(v), theta.numel(), int(t), lr, beta1, beta2, eps, grad_scale, _s()), "adam")
 
 
-def adam_iter(theta, g, m, v, iterations, lr=1e-3, beta1=0.5, beta2=0.999, eps=1e-7, grad_scale=1.0):
-    """Adam with the step number kept on the device (``iterations``: 1-element int64 tensor, incremented by the call)."""
+def adam_iter(theta, g, m, v, state, lr=1e-3, beta1=0.5, beta2=0.999, eps=1e-7, grad_scale=1.0):
+    """Adam with the step number kept on the device (``state``: int64[2] = [iterations, scratch]; iterations is incremented)."""
     assert theta.dtype == torch.float32 and theta.numel() == g.numel() == m.numel() == v.numel()
-    assert iterations.dtype == torch.int64 and iterations.numel() == 1
-    A.check(A.lib().sgg_adam_iter(_p(theta), _p(g), _p(m), _p(v), theta.numel(), _p(iterations), lr, beta1, beta2, eps, grad_scale, _s()), "adam_iter")
+    assert state.dtype == torch.int64 and state.numel() == 2
+    A.check(A.lib().sgg_adam_iter(_p(theta), _p(g), _p(m), _p(v), theta.numel(), _p(state), lr, beta1, beta2, eps, grad_scale, _s()), "adam_iter")
 
 
 # ----------------------------------------------------------------------------- data side

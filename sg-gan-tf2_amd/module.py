@@ -46,7 +46,8 @@ class ParamStore:
         self.version = 0            # bumped whenever parameter values change (re-pack trigger)
         # Adam's step number lives on the device (Keras: the `optimizer.iterations` variable), so the update launch
         # carries no host state and can be replayed from a captured HIP graph
-        self.iterations = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._adam_state = torch.zeros(2, dtype=torch.int64, device=self.device)    # [iterations, scratch] (sgg_adam_iter)
+        self.iterations = self._adam_state[0:1]
 
     @property
     def step_count(self):
@@ -116,7 +117,7 @@ class ParamStore:
 
     def adam_step(self, lr=1e-3, beta1=0.5, beta2=0.999, eps=1e-7, grad_scale=1.0):
         """tf.keras.optimizers.Adam.apply_gradients (model.py:199-200) over the whole network: one launch."""
-        K.adam_iter(self.flat, self.grad, self.m, self.v, self.iterations, lr, beta1, beta2, eps, grad_scale)
+        K.adam_iter(self.flat, self.grad, self.m, self.v, self._adam_state, lr, beta1, beta2, eps, grad_scale)
         self.version += 1
 
 

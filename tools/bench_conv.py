@@ -15,11 +15,12 @@ ap.add_argument("--iters", type=int, default=50); ap.add_argument("--ops", defau
 a = ap.parse_args()
 dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 pad, refl = ("VALID", int(a.pad.split("-")[1])) if a.pad.startswith("REFLECT") else (a.pad, 0)
-g = K.conv_geom(a.n, a.h, a.w, a.c, a.k, a.r, a.r, a.stride, pad, refl, dt)
+Cp, Kp = K.cpad(a.c), K.cpad(a.k)          # channel counts are stored padded to 8 (3 -> 8)
+g = K.conv_geom(a.n, a.h, a.w, Cp, Kp, a.r, a.r, a.stride, pad, refl, dt)
 x = torch.randn(g.x_shape, device="cuda").to(dt)
 dy = torch.randn(g.y_shape, device="cuda").to(dt)
 w = torch.randn((a.r, a.r, a.c, a.k), device="cuda") / (a.r * a.r * a.c) ** 0.5
-wf, wd = K.pack_weights(w, a.c, a.k, dt)
+wf, wd = K.pack_weights(w, Cp, Kp, dt)
 dw = torch.empty_like(w)
 flops = 2.0 * g.y_shape[0] * g.y_shape[1] * g.y_shape[2] * a.k * a.r * a.r * a.c
 fns = {"fwd": lambda: K.conv_fwd(g, x, wf, None), "dgrad": lambda: K.conv_dgrad(g, dy, wd), "wgrad": lambda: K.conv_wgrad(g, x, dy, dw)}

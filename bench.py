@@ -258,6 +258,7 @@ def main():
     ap.add_argument("--mode", default="cycle", choices=["cycle", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--mixed", type=int, default=0, help="1: bf16 storage with the f32 activation-gradient chain through the residual blocks (sggan mixed=True)")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step from captured HIP graphs (default); 0: eager per-launch dispatch from Python")
     a = ap.parse_args()
 
@@ -281,7 +282,7 @@ def main():
     from sggan_amd import kernels as K
     def make_model(mode):
         m = sggan_amd.sggan(sggan_amd.default_args(dtype=a.dtype, device=f"cuda:{local}", image_height=a.height,
-                                                   image_width=a.width, batch_size=a.batch, cycle=(mode == "cycle"), graph=bool(a.graph)))
+                                                   image_width=a.width, batch_size=a.batch, cycle=(mode == "cycle"), graph=bool(a.graph), mixed=bool(a.mixed)))
         if dist is not None:
             m.enable_data_parallel()
         set_inputs(m, a.batch, a.height, a.width, 19 + rank)
@@ -349,7 +350,7 @@ def main():
             "config": {"workload": f"BASELINE configs[2]: {what}, 9-block ResNet generators, "
                                    f"{a.width}x{a.height}, batch {a.batch}/GPU, {a.dtype} storage / f32 accumulate", "mode": a.mode,
                        "global_batch": a.batch * world, "height": a.height, "width": a.width, "parallelism": f"dp{world}",
-                       "gflop_per_image": gflop_img,
+                       "gflop_per_image": gflop_img, "mixed_gradient_chain": bool(a.mixed),
                        "dispatch": (f"HIP-graph replay of the recorded step (sggan_amd/graph.py) for {a.steps - eager_tail} of the {a.steps} timed "
                                     f"steps, eager launches for the last {eager_tail} (the ones whose kernels are timed with events)"
                                     if a.graph else "eager launches from Python")},

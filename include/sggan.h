@@ -107,6 +107,14 @@ size_t sgg_conv2d_bwd_data_stats_chunks(const sgg_conv_desc* d);
 int sgg_conv2d_bwd_data_stats(const sgg_conv_desc* d, const void* dy, const void* w_dgrad, const void* addend, void* dx,
                               const void* norm_x, const float* norm_stats, const float* norm_gamma, const float* norm_beta,
                               int norm_act, float norm_leak, float* partial, void* ws, size_t ws_bytes, void* stream);
+/* Mixed-precision data gradient (an extension; the reference trains in f32 throughout, gen_tape.gradient model.py:196):
+ * bf16 operands, dx written in F32 -- and the addend read as f32 when addend_is_f32 -- so that the gradient chain
+ * between the instance norms of the residual blocks is not re-rounded to bf16 at every layer (the norm backward
+ * subtracts most of dy; a rounding relative to dy is amplified there).  Supported where
+ * sgg_conv2d_bwd_data_mixed_supported(d) returns 1 (the bf16 3x3 stride-1 kernel); ws as for sgg_conv2d_bwd_data. */
+int sgg_conv2d_bwd_data_mixed_supported(const sgg_conv_desc* d);
+int sgg_conv2d_bwd_data_mixed(const sgg_conv_desc* d, const void* dy, const void* w_dgrad, const void* addend, int addend_is_f32,
+                              float* dx, void* ws, size_t ws_bytes, void* stream);
 /* bwd_weight: dw_hwio[R][S][C_real][K_real] f32, overwritten (accumulate=0) or added to (accumulate=1: a network
  * applied twice in one step, model.py:186-187).  ws: sgg_conv2d_bwd_weight_workspace() bytes. */
 size_t sgg_conv2d_bwd_weight_workspace(const sgg_conv_desc* d);
@@ -157,6 +165,10 @@ int sgg_instnorm_fwd_partial(const void* x, const float* gamma, const float* bet
 int sgg_instnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats,
                      void* dx, float* dgamma, float* dbeta, int N, int64_t HW, int C, int C_real, int accumulate,
                      int act, float leak, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* the same for an F32 dy against bf16 x / dx (mixed mode, see sgg_conv2d_bwd_data_mixed) */
+int sgg_instnorm_bwd_mixed(const float* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
+                           float* dgamma, float* dbeta, int N, int64_t HW, int C, int C_real, int accumulate, int act, float leak,
+                           void* ws, size_t ws_bytes, void* stream);
 /* same, with the statistics pass replaced by precomputed partial sums partial[N][chunks][C][2] (sgg_conv2d_bwd_data_stats);
  * ws >= N*C*4 floats */
 int sgg_instnorm_bwd_partial(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,

@@ -47,6 +47,8 @@ SIGNATURES = {
     "sgg_conv2d_bwd_data": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgg_conv2d_bwd_data_stats_chunks": (_sz, [_dp]),
     "sgg_conv2d_bwd_data_stats": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _sz, _vp]),
+    "sgg_conv2d_bwd_data_mixed_supported": (_i, [_dp]),
+    "sgg_conv2d_bwd_data_mixed": (_i, [_dp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "sgg_conv2d_bwd_weight_workspace": (_sz, [_dp]),
     "sgg_conv2d_bwd_weight": (_i, [_dp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sgg_conv2d_bwd_weight_pair_supported": (_i, [_dp]),
@@ -62,6 +64,7 @@ SIGNATURES = {
     "sgg_instnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _i, _f, _i, _vp, _sz, _vp]),
     "sgg_instnorm_fwd_partial": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _f, _i, _f, _i, _vp]),
     "sgg_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
+    "sgg_instnorm_bwd_mixed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "sgg_instnorm_bwd_partial": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "sgg_act_fwd": (_i, [_vp, _vp, _i64, _i, _f, _i, _vp]),
     "sgg_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _f, _i, _vp]),

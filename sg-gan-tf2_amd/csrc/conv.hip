@@ -48,6 +48,8 @@ struct ConvArgs {
     int nact; float nleak;   // and the activation fused behind it
     float* partial;      // split-K (v2): f32 slabs [ksplit][pdst][DC]
     int ksplit;          // 1 = no split
+    int dst_f32;         // halo 3x3 data gradient, mixed mode: dst is f32 (the gradient chain between instance norms keeps f32)
+    int addend_f32;      //   ... and so is the addend
     int ablate;          // lab build only (SGG_ABLATE; always 0 and compiled out otherwise): 1 no in-loop DMA, 2 no LDS reads/MFMAs, 3 = 1 + no barrier,
                          // 5 prologue + epilogue only, 6 prologue only (results in DESIGN.md section 7)
     size_t pdst;         // destination pixels (slab stride)
@@ -968,9 +970,19 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[i][j][e] + bv[i][e], a.act, a.leak);
                 if (a.addend) {
-                    const bf16* ad = reinterpret_cast<const bf16*>(a.addend) + dpix * DC + dc;
+                    if (MODE != MODE_FWD && a.addend_f32) {
+                        const f32x4 ad = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.addend) + dpix * DC + dc);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)ad[e];
+                        for (int e = 0; e < 4; ++e) v[e] += ad[e];
+                    } else {
+                        const bf16* ad = reinterpret_cast<const bf16*>(a.addend) + dpix * DC + dc;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)ad[e];
+                    }
+                }
+                if (MODE != MODE_FWD && a.dst_f32) {      // mixed mode: the data gradient stays f32 on its way to the next norm backward
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.dst) + dpix * DC + dc) = (f32x4){v[0], v[1], v[2], v[3]};
+                    continue;
                 }
                 bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.dst) + dpix * DC + dc) = pk;
@@ -1738,12 +1750,19 @@ __global__ __launch_bounds__(512) void wgrad7_kernel(W7Args a) {
         for (int i = 0; i < RS; ++i) {
             const char* raw = smem + Cfg::OFF_BRAW + ((step & 3) * RS + i) * 512;   // [part 0..1][pixel] dwords
             uint32_t lo[7], hi[7];                                             // pixel q - s: channels (0,1) and (2,3)
+            // (unconditional loads from a clamped index + a select: a conditional load becomes a branch with a full
+            // lgkmcnt(0) wait behind every read, ~2 000 cycles per row)
 #pragma unroll
             for (int sc = 0; sc < 7; ++sc) {
-                const int idx = q - sc;
-                const bool ok = idx >= 0;
-                lo[sc] = ok ? *reinterpret_cast<const uint32_t*>(raw + 4 * idx) : 0u;
-                hi[sc] = ok ? *reinterpret_cast<const uint32_t*>(raw + 256 + 4 * idx) : 0u;
+                const int idx = q - sc, ic = idx < 0 ? 0 : idx;
+                lo[sc] = *reinterpret_cast<const uint32_t*>(raw + 4 * ic);
+                hi[sc] = *reinterpret_cast<const uint32_t*>(raw + 256 + 4 * ic);
+            }
+#pragma unroll
+            for (int sc = 0; sc < 7; ++sc) {
+                const bool ok = q - sc >= 0;
+                lo[sc] = ok ? lo[sc] : 0u;
+                hi[sc] = ok ? hi[sc] : 0u;
             }
             // columns n = j*8 + s: 16-byte chunk j holds s = 0..6 (+ a zero) for channel j; chunk 3 is zero
             u32x4 ch[3];
@@ -2798,7 +2817,7 @@ static bool desc_ok(const sgg_conv_desc* d) {
 
 static ConvArgs make_args(const sgg_conv_desc* d, const void* src, const void* w, const float* bias, void* dst, int act, float leak) {
     ConvArgs a;
-    a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst; a.addend = nullptr; a.fold = nullptr; a.stats = nullptr; a.nx = nullptr; a.nstats = nullptr; a.ngamma = nullptr; a.nbeta = nullptr; a.nact = 0; a.nleak = 0.f; a.partial = nullptr; a.ksplit = 1; a.pdst = 0;
+    a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst; a.addend = nullptr; a.fold = nullptr; a.stats = nullptr; a.nx = nullptr; a.nstats = nullptr; a.ngamma = nullptr; a.nbeta = nullptr; a.nact = 0; a.nleak = 0.f; a.partial = nullptr; a.ksplit = 1; a.pdst = 0; a.dst_f32 = 0; a.addend_f32 = 0;
     a.ablate = sgg_config().ablate;
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S; a.stride = d->stride;
     a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.reflect = d->pad_mode == SGG_PAD_REFLECT;
@@ -3567,13 +3586,14 @@ size_t sgg_conv2d_bwd_data_workspace(const sgg_conv_desc* d) {
     return fold_bytes(d) + plan_gemm(d, MODE_DGRAD).ws_bytes;
 }
 
-struct NormBwdStats { const void* nx; const float* nstats; const float* ngamma; const float* nbeta; int nact; float nleak; float* partial; };
+struct NormBwdStats { const void* nx; const float* nstats; const float* ngamma; const float* nbeta; int nact; float nleak; float* partial; int mixed; };
 
 static int conv2d_bwd_data_impl(const sgg_conv_desc* d, const void* dy, const void* w, const void* addend, void* dx, const NormBwdStats* nb,
                                 void* ws, size_t ws_bytes, void* stream) {
     if (!desc_ok(d) || !dy || !w || !dx) return SGG_EINVAL;
     ConvArgs a = make_args(d, dy, w, nullptr, dx, SGG_ACT_NONE, 0.f);
     a.addend = (const char*)addend;
+    if (nb && nb->mixed) { a.dst_f32 = nb->mixed & 1; a.addend_f32 = (nb->mixed >> 1) & 1; nb = nullptr; }
     if (nb) {
         a.stats = nb->partial; a.nx = (const char*)nb->nx; a.nstats = nb->nstats; a.ngamma = nb->ngamma; a.nbeta = nb->nbeta;
         a.nact = nb->nact; a.nleak = nb->nleak;
@@ -3635,6 +3655,20 @@ int sgg_conv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w, c
     return conv2d_bwd_data_impl(d, dy, w, addend, dx, nullptr, ws, ws_bytes, stream);
 }
 
+// Mixed-precision data gradient (bf16 operands, f32 result): only the LDS-resident 3x3 halo GEMM has the epilogue
+int sgg_conv2d_bwd_data_mixed_supported(const sgg_conv_desc* d) {
+    if (!desc_ok(d) || d->dtype != SGG_BF16) return 0;
+    ConvArgs a = make_args(d, nullptr, nullptr, nullptr, nullptr, SGG_ACT_NONE, 0.f);
+    return (plan_gemm(d, MODE_DGRAD).ksplit == 1 && halo3_ok(a, MODE_DGRAD, true)) ? 1 : 0;
+}
+int sgg_conv2d_bwd_data_mixed(const sgg_conv_desc* d, const void* dy, const void* w, const void* addend, int addend_is_f32, float* dx,
+                              void* ws, size_t ws_bytes, void* stream) {
+    if (!sgg_conv2d_bwd_data_mixed_supported(d)) return SGG_EUNSUPPORTED;
+    NormBwdStats flags{};                            // nb == nullptr semantics, but carries the two mixed flags
+    flags.mixed = 1 | (addend_is_f32 ? 2 : 0);
+    return conv2d_bwd_data_impl(d, dy, w, addend, dx, &flags, ws, ws_bytes, stream);
+}
+
 // Pixel chunks per image of the instance-norm-backward partial sums sgg_conv2d_bwd_data_stats() emits; 0 = unsupported shape
 size_t sgg_conv2d_bwd_data_stats_chunks(const sgg_conv_desc* d) {
     if (!desc_ok(d) || d->dtype != SGG_BF16) return 0;
@@ -3649,7 +3683,7 @@ int sgg_conv2d_bwd_data_stats(const sgg_conv_desc* d, const void* dy, const void
     if (!norm_x || !norm_stats || !norm_gamma || !norm_beta || !partial) return SGG_EINVAL;
     if (norm_act == SGG_ACT_TANH) return SGG_EUNSUPPORTED;
     if (sgg_conv2d_bwd_data_stats_chunks(d) == 0) return SGG_EUNSUPPORTED;
-    NormBwdStats nb{norm_x, norm_stats, norm_gamma, norm_beta, norm_act, norm_leak, partial};
+    NormBwdStats nb{norm_x, norm_stats, norm_gamma, norm_beta, norm_act, norm_leak, partial, 0};
     return conv2d_bwd_data_impl(d, dy, w, addend, dx, &nb, ws, ws_bytes, stream);
 }
 

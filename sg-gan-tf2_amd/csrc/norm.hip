@@ -15,6 +15,19 @@
 // visible against the float64 oracle (tools/diag_d_f32.py).  On the bf16 path the operands carry 8 bits: f32 is plenty.
 template <typename T> using InAcc = typename std::conditional<std::is_same<T, float>::value, double, float>::type;
 
+// The incoming gradient dy normally has the tensor's storage type T.  Mixed mode (bf16 tensors, f32 gradient chain): dy is
+// f32 -- the VEC channels of a 16-byte chunk of x are then two 16-byte chunks of dy.  `elem` = element index of the chunk.
+template <typename T, typename TG>
+__device__ inline void in_load_grad(const char* dy, size_t elem, float* gv) {
+    if constexpr (std::is_same<T, TG>::value) {
+        ET<T>::unpack(ld16(dy + elem * sizeof(T)), gv);
+    } else {
+        static_assert(std::is_same<TG, float>::value && ET<T>::VEC == 8, "mixed mode: f32 gradient of a bf16 tensor");
+        ET<float>::unpack(ld16(dy + elem * 4), gv);
+        ET<float>::unpack(ld16(dy + elem * 4 + 16), gv + 4);
+    }
+}
+
 // pixels per partial-sum chunk: >= 64, and large enough that an image has at most ~128 chunks (the finalize kernels
 // walk the chunks of one channel serially: 2048 chunks cost 68 us on a 256x512x64 tensor, 128 chunks 5 us)
 static inline int in_rows_per_chunk(int64_t HW) {
@@ -25,7 +38,7 @@ static inline int in_rows_per_chunk(int64_t HW) {
 // ws layout: partial[N][chunks][C][2] f32, then sums[N][C][2] and tot[N][C][2] f32 (bwd only)
 static inline int in_chunks(int64_t HW) { int r = in_rows_per_chunk(HW); return (int)((HW + r - 1) / r); }
 
-template <typename T, bool BWD>
+template <typename T, bool BWD, typename TG = T>
 __global__ __launch_bounds__(256) void in_partial_kernel(const char* x, const char* dy, const float* gamma, const float* beta,
                                                          const float* stats, float* partial, int64_t HW, int C, int chunks,
                                                          int rpc, int act, float leak) {
@@ -63,7 +76,7 @@ __global__ __launch_bounds__(256) void in_partial_kernel(const char* x, const ch
                     for (int e = 0; e < VEC; ++e) { s1[e] += (AccT)xv[e]; s2[e] += (AccT)xv[e] * (AccT)xv[e]; }
                 } else {
                     float gv[VEC];
-                    ET<T>::unpack(ld16(dy + off), gv);
+                    in_load_grad<T, TG>(dy, off / sizeof(T), gv);
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
                         float xh = (xv[e] - mu[e]) * rs[e];
@@ -146,7 +159,7 @@ __device__ inline void in_param_grad(const InParamGrad& g, int C) {
     }
 }
 
-template <typename T, bool BWD>
+template <typename T, bool BWD, typename TG = T>
 __global__ __launch_bounds__(256) void in_apply_kernel(const char* x, const char* dy, const char* residual, const float* gamma,
                                                        const float* beta, const float* stats, const float* sums, char* out,
                                                        int64_t HW, int C, int rows_per_block, int act, float leak, InParamGrad pg) {
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const char* x, const char
                 }
             } else {
                 float gv[VEC];
-                ET<T>::unpack(ld16(dy + off), gv);
+                in_load_grad<T, TG>(dy, off / sizeof(T), gv);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     float xh = (xv[e] - mu[e]) * rs[e];
@@ -413,6 +426,29 @@ int sgg_instnorm_bwd(const void* dy, const void* x, const float* gamma, const fl
         hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, sums, tot, HW, C, chunks);
         hipLaunchKernelGGL((in_apply_kernel<float, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg);
     } else return SGG_EINVAL;
+    return sgg_check_launch();
+}
+
+// Mixed mode: dy is f32, x / dx are bf16 (the gradient chain between the instance norms of the residual blocks stays f32:
+// the norm backward subtracts the mean and the xhat-correlated part of dy, so a bf16 rounding of dy -- relative to dy, not
+// to what is left of it -- is amplified there layer after layer).  Same passes as sgg_instnorm_bwd.
+int sgg_instnorm_bwd_mixed(const float* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
+                           float* dgamma, float* dbeta, int N, int64_t HW, int C, int C_real, int accumulate, int act, float leak,
+                           void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !gamma || !beta || !stats || !dx || !dgamma || !dbeta || N <= 0 || HW <= 0 || C <= 0 || C % SGG_CPAD || C_real <= 0 || C_real > C) return SGG_EINVAL;
+    if (act == SGG_ACT_TANH) return SGG_EUNSUPPORTED;
+    if (!ws || ws_bytes < sgg_instnorm_workspace(N, HW, C)) return SGG_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    int chunks = in_chunks(HW);
+    float* partial = (float*)ws;
+    float* sums = partial + (size_t)N * chunks * C * 2;
+    float* tot = sums + (size_t)N * C * 2;
+    int rpb = in_rows_per_block(N, HW, C, 0);
+    dim3 gp(chunks, N), ga((unsigned)((HW + rpb - 1) / rpb), N);
+    const InParamGrad pg{tot, dgamma, dbeta, N, C_real, accumulate};
+    hipLaunchKernelGGL((in_partial_kernel<bf16, true, float>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
+    hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, sums, tot, HW, C, chunks);
+    hipLaunchKernelGGL((in_apply_kernel<bf16, true, float>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg);
     return sgg_check_launch();
 }
 

@@ -87,7 +87,7 @@ def same_pads(n_in: int, k: int, s: int):
 
 class ConvGeom:
     """Geometry of one Conv2D / Conv2DTranspose call site, resolved to an sgg_conv_desc."""
-    __slots__ = ("desc", "x_shape", "y_shape", "ws_wgrad", "ws_dgrad", "ws_fwd", "dtype", "is_deconv", "stats_chunks", "wgrad_pair", "bwd_stats_chunks")
+    __slots__ = ("desc", "x_shape", "y_shape", "ws_wgrad", "ws_dgrad", "ws_fwd", "dtype", "is_deconv", "stats_chunks", "wgrad_pair", "bwd_stats_chunks", "dgrad_mixed")
 
     def __init__(self, desc, x_shape, y_shape, dtype, is_deconv):
         self.desc, self.x_shape, self.y_shape, self.dtype, self.is_deconv = desc, x_shape, y_shape, dtype, is_deconv
@@ -99,6 +99,8 @@ class ConvGeom:
         self.wgrad_pair = (not is_deconv) and bool(L.sgg_conv2d_bwd_weight_pair_supported(C.byref(desc)))
         # chunks of the norm-backward partial sums the data gradient can emit for the norm that consumes dx (0: it cannot)
         self.bwd_stats_chunks = 0 if is_deconv else int(L.sgg_conv2d_bwd_data_stats_chunks(C.byref(desc)))
+        # mixed mode: the data gradient can be written in f32 (bf16 operands) for the norm backward that consumes it
+        self.dgrad_mixed = (not is_deconv) and bool(L.sgg_conv2d_bwd_data_mixed_supported(C.byref(desc)))
         # workspaces of the two GEMM directions; a deconv runs the conv's data-gradient kernel forwards
         self.ws_fwd = int((L.sgg_deconv2d_fwd_workspace if is_deconv else L.sgg_conv2d_fwd_workspace)(C.byref(desc)))
         self.ws_dgrad = int((L.sgg_deconv2d_bwd_data_workspace if is_deconv else L.sgg_conv2d_bwd_data_workspace)(C.byref(desc)))
@@ -198,14 +200,25 @@ def conv_fwd_stats(g: ConvGeom, x, w_fwd, bias):
     return y, partial
 
 
-def conv_dgrad(g: ConvGeom, dy, w_dgrad, addend=None):
-    """dx = conv^T(dy) (+ addend: the skip-connection gradient, fused into the epilogue)."""
+def conv_dgrad(g: ConvGeom, dy, w_dgrad, addend=None, out_f32=False):
+    """dx = conv^T(dy) (+ addend: the skip-connection gradient, fused into the epilogue).  out_f32 (mixed mode, needs
+    g.dgrad_mixed): bf16 operands, dx in float32; the addend may then be bf16 or float32."""
     assert tuple(dy.shape) == g.y_shape and not g.is_deconv
+    pr = _prof("conv2d_bwd_data", g)
+    ws = workspace(g.ws_dgrad, dy.device) if g.ws_dgrad else None
+    if out_f32:
+        assert g.dgrad_mixed and dy.dtype == torch.bfloat16
+        assert addend is None or (tuple(addend.shape) == g.x_shape and addend.dtype in (torch.bfloat16, torch.float32))
+        dx = torch.empty(g.x_shape, dtype=torch.float32, device=dy.device)
+        if pr: pr.start()
+        A.check(A.lib().sgg_conv2d_bwd_data_mixed(C.byref(g.desc), _p(dy), _p(w_dgrad), _p(addend),
+                                                  int(addend is not None and addend.dtype == torch.float32), _p(dx), _p(ws), g.ws_dgrad, _s()),
+                "conv2d_bwd_data_mixed")
+        if pr: pr.stop()
+        return dx
     assert addend is None or (tuple(addend.shape) == g.x_shape and addend.dtype == dy.dtype)
     dx = torch.empty(g.x_shape, dtype=dy.dtype, device=dy.device)
-    pr = _prof("conv2d_bwd_data", g)
     if pr: pr.start()
-    ws = workspace(g.ws_dgrad, dy.device) if g.ws_dgrad else None
     A.check(A.lib().sgg_conv2d_bwd_data(C.byref(g.desc), _p(dy), _p(w_dgrad), _p(addend), _p(dx), _p(ws), g.ws_dgrad, _s()), "conv2d_bwd_data")
     if pr: pr.stop()
     return dx
@@ -318,6 +331,10 @@ def instnorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, accumulate=False, act
     N, H, W, Cp = x.shape
     dx = torch.empty_like(x)
     ws = workspace(int(A.lib().sgg_instnorm_workspace(N, H * W, Cp)), x.device)
+    if dy.dtype == torch.float32 and x.dtype == torch.bfloat16:        # mixed mode: f32 gradient chain, bf16 tensors
+        A.check(A.lib().sgg_instnorm_bwd_mixed(_p(dy), _p(x), _p(gamma), _p(beta), _p(stats), _p(dx), _p(dgamma), _p(dbeta), N, H * W, Cp,
+                                               dgamma.numel(), int(accumulate), act, leak, _p(ws), ws.numel(), _s()), "instnorm_bwd_mixed")
+        return dx
     A.check(A.lib().sgg_instnorm_bwd(_p(dy), _p(x), _p(gamma), _p(beta), _p(stats), _p(dx), _p(dgamma), _p(dbeta), N, H * W, Cp,
                                      dgamma.numel(), int(accumulate), act, leak, dt(x), _p(ws), ws.numel(), _s()), "instnorm_bwd")
     return dx

@@ -29,7 +29,7 @@ def default_args(**over):
     a = dict(batch_size=1, image_height=128, image_width=128, input_nc=3, output_nc=3, ngf=64, ndf=64,
              segment_class=34, beta1=0.5, lr=0.0002, L1_lambda=10.0, Lg_lambda=5.0, use_resnet=True, use_pix2pix=False,
              use_lsgan=True, ratio_gan2seg=10, max_size=50, phase="train", dataset_dir="city",
-             dtype="bf16", device="cuda", n_blocks=9, seed=19, graph=False)
+             dtype="bf16", device="cuda", n_blocks=9, seed=19, graph=False, mixed=False)
     a.update(over)
     return SimpleNamespace(**a)
 
@@ -93,6 +93,10 @@ class sggan(object):
         if self.cycle:
             self.g_optim_BA = Adam(self.generator_BA, lr, self.beta1)
             self.d_optim_B = Adam(self.discriminator_B, lr, self.beta1)
+        # mixed precision: bf16 storage, but the activation-gradient chain through the generators' residual blocks in f32
+        self.mixed = bool(g("mixed", False)) and self.dtype == torch.bfloat16
+        for net in self.networks():
+            net.mixed = self.mixed
         # HIP-graph replay of the step (graph.py): recorded at the first train_step after enable_graph()
         self.use_graph = bool(g("graph", False))
         self._program = None

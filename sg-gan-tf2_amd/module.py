@@ -289,6 +289,8 @@ class _ConvUnit:
                 dxc = K.instnorm_bwd(dy, xc, P.p(n + "_g"), P.p(n + "_beta"), stats, dg, db, param_grads, self.act, self.leak)
             # the conv bias feeds an InstanceNorm: its gradient is identically 0 -> left at 0
         else:
+            if dy.dtype != xc.dtype:
+                dy = dy.to(xc.dtype)
             dxc = K.act_bwd(dy, xc, self.act, self.leak) if self.act != A.ACT_NONE else dy
             if param_grads:
                 K.bias_grad(dxc, P.g(n + "_b", buf=gbuf), accumulate=True)
@@ -311,16 +313,21 @@ class _ConvUnit:
         if not want_dx:
             return None
         if self.kind == "conv":
+            # mixed mode: the gradient handed to the NEXT norm backward stays f32 (bf16 operands in the GEMM, f32 result)
+            out_f32 = bool(self.net.mixed and next_norm is not None and next_norm[0].norm and g.dgrad_mixed and dxc.dtype == torch.bfloat16)
+            if addend is not None and addend.dtype != dxc.dtype and not out_f32:
+                addend = addend.to(dxc.dtype)
             if next_norm is not None:
                 nu, nrec = next_norm
-                if FUSE_CONV_IN_STATS and FUSE_CONV_IN_BWD and g.bwd_stats_chunks and nu.norm and tuple(nrec[2].shape) == g.x_shape:
+                if (not out_f32 and FUSE_CONV_IN_STATS and FUSE_CONV_IN_BWD and g.bwd_stats_chunks and nu.norm
+                        and tuple(nrec[2].shape) == g.x_shape):
                     NP = nu.net.P
                     return K.conv_dgrad_stats(g, dxc, wd, addend, nrec[2], nrec[3], NP.p(nu.name + "_g"), NP.p(nu.name + "_beta"),
                                               nu.act, nu.leak)
-                return K.conv_dgrad(g, dxc, wd, addend), None
+                return K.conv_dgrad(g, dxc, wd, addend, out_f32=out_f32), None
             return K.conv_dgrad(g, dxc, wd, addend)
         dx = K.deconv_dgrad(g, dxc, wf)
-        dx = dx if addend is None else K.add(dx, addend)
+        dx = dx if addend is None else K.add(dx, addend.to(dx.dtype))
         return (dx, None) if next_norm is not None else dx
 
 
@@ -340,6 +347,9 @@ class _Net:
         # set by a step that applies this net exactly twice (the cycle step): weight gradients of layers that support
         # it are deferred at the first backward and run with the second as one launch (_ConvUnit.backward)
         self.pair_wgrads = False
+        # mixed precision (bf16 networks only): data gradients that feed an instance-norm backward are kept in f32 where the
+        # kernel supports it (the residual chain) -- see sgg_conv2d_bwd_data_mixed in include/sggan.h
+        self.mixed = False
         self._pack_tables = {}
 
     def conv_units(self):

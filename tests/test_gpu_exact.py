@@ -139,3 +139,29 @@ def test_residual_conv_fused_variants_bit_exact_at_bench_shape(sg):
     dw = torch.full((3, 3, C, C), 5.0, device="cuda")
     K.conv_wgrad_pair(g, dev(x0, bf), dev(dy0, bf), dev(x1, bf), dev(dy1, bf), dw, accumulate=True)
     same(dw, res[0][2] + res[1][2] + 5.0, "wgrad pair")
+
+
+def test_mixed_precision_data_gradient_is_exact_f32_at_bench_shape(sg):
+    """Mixed mode (sgg_conv2d_bwd_data_mixed): bf16 operands, F32 result.  With integer inputs the result must equal the
+    oracle's exact integers WITHOUT any rounding -- the REFLECT fold and a float32 skip-gradient addend included."""
+    from sggan_amd import kernels as K
+    N, H, W, C = 8, 64, 128, 256
+    rng = np.random.default_rng(78)
+    x, w, b = ints(rng, (N, H, W, C)), ints(rng, (3, 3, C, C)), ints(rng, (C,), -2, 2)
+    dy = ints(rng, (N, H, W, C), -4, 4)
+    add = ints(rng, (N, H, W, C), -1000, 1000) + 0.5          # not representable in bf16: the addend really is read as f32
+    t = O.Tape()
+    vx, vw, vb = O.Var(x), O.Var(w), O.Var(b)
+    y = O.conv2d(t, vx, vw, vb, 1, "VALID", 1)
+    t.backward([(y, dy)])
+    assert np.abs(vx.g).max() > 256                            # above bf16's exact-integer range: a bf16 store would round
+    g = K.conv_geom(N, H, W, C, C, 3, 3, 1, "VALID", 1, torch.bfloat16)
+    assert g.dgrad_mixed
+    _, wd = K.pack_weights(dev(w), C, C, torch.bfloat16)
+    dx = K.conv_dgrad(g, dev(dy, torch.bfloat16), wd, None, out_f32=True)
+    assert dx.dtype == torch.float32
+    same(dx, vx.g, "mixed dgrad")
+    dx2 = K.conv_dgrad(g, dev(dy, torch.bfloat16), wd, dev(add), out_f32=True)
+    same(dx2, vx.g + add, "mixed dgrad + f32 addend")
+    dx3 = K.conv_dgrad(g, dev(dy, torch.bfloat16), wd, dev(np.round(add / 8), torch.bfloat16), out_f32=True)
+    same(dx3, vx.g + np.round(add / 8), "mixed dgrad + bf16 addend")

@@ -278,6 +278,35 @@ def test_activations(sg, dtype):
         close(tx.grad.detach().float().cpu().numpy(), dref(xf), dtype, "dact")
 
 
+def test_instnorm_bwd_mixed_f32_gradient_of_bf16_tensor(sg):
+    """sgg_instnorm_bwd_mixed: dy in float32 against a bf16 tensor (mixed mode) vs the oracle on the same bf16-rounded x and the
+    f32 dy; dgamma / dbeta (f32) at 1e-4, dx (stored bf16) at one bf16 rounding."""
+    from sggan_amd import kernels as K, _abi as A
+    rng = np.random.default_rng(12)
+    for shape, act in (((2, 16, 64, 64), A.ACT_RELU), ((1, 40, 24, 256), A.ACT_NONE), ((2, 5, 7, 32), A.ACT_LRELU)):
+        C = shape[-1]
+        tx = dev(rng.standard_normal(shape) * 1.5 + 0.3, torch.bfloat16)
+        xq = tx.float().cpu().numpy().astype(np.float64)
+        dy = rng.standard_normal(shape).astype(np.float32)
+        gam, bet = (1 + 0.2 * rng.standard_normal(C)).astype(np.float32), (0.2 * rng.standard_normal(C)).astype(np.float32)
+        t = O.Tape()
+        vx, vg, vb = V(xq), V(gam), V(bet)
+        y = O.instance_norm(t, vx, vg, vb, 1e-3)
+        if act == A.ACT_RELU:
+            y = O.relu(t, y)
+        elif act == A.ACT_LRELU:
+            y = O.lrelu(t, y, 0.3)
+        t.backward([(y, dy.astype(np.float64))])
+        _, st = K.instnorm_fwd(tx, dev(gam), dev(bet), None, 1e-3, act, 0.3)
+        dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        dx = K.instnorm_bwd(dev(dy), tx, dev(gam), dev(bet), st, dg, db, False, act, 0.3)
+        assert dx.dtype == torch.bfloat16
+        close(dg.cpu().numpy(), vg.g, torch.float32, "dgamma", scale=np.abs(vg.g).max())
+        close(db.cpu().numpy(), vb.g, torch.float32, "dbeta", scale=max(np.abs(vb.g).max(), 1e-3 * np.abs(dy).sum() / C))
+        err = np.abs(dx.float().cpu().numpy() - vx.g).max() / np.abs(vx.g).max()
+        assert err < 6e-3, (shape, err)                      # one bf16 rounding of the result (2^-8 = 3.9e-3 of the value)
+
+
 def test_seg_class_map_reference_fixtures_bit_exact(sg):
     sc = sg.segment_class
     z = np.load(os.path.join(G, "segclass_gta.npz"))

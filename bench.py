@@ -80,10 +80,10 @@ def set_inputs(model, N, H, W, seed):
 
 
 def measured_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json: FETCH_SIZE doubled per
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_traffic.json: FETCH_SIZE doubled per
     MI355X_MICROARCH.md + WRITE_SIZE, separate --pmc passes on tools/bench_conv.py); None if not collected."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
             return json.load(f)[kernel]["hbm_bytes_per_launch"]
     except Exception:
         return None

@@ -1018,7 +1018,23 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         }
         return;
     }
-    // STATS 2 (opt-in): one 16-channel group at a time, to keep that group's norm constants in registers
+    // STATS 2: one 16-channel group at a time, to keep that group's norm constants in registers.  The norm's input tile
+    // (2 rows x 128 pixels x 256 channels = 128 KB) is first DMA'd into LDS -- the halo and the weight stages are free now --
+    // with coalesced 16-byte pieces, and each lane then picks its 8-byte (pixel, 4 channels) groups out of LDS.  (Reading
+    // them straight from global memory, 32 scattered 8-byte loads per lane, cost +27 us per launch.)  512-byte pixel rows,
+    // 16-byte chunk c of pixel p at position c ^ (p & 31): the 16 pixels a ds_read_b64 touches hit 16 different chunks.
+    if constexpr (STATS == 2) {
+        for (int id = wave; id < 128; id += 8) {         // 128 wave-instructions of 2 pixels x 512 B
+            const int p = id * 2 + (lane >> 5), pos = lane & 31;
+            const int chunk = pos ^ (p & 31);
+            const bool ok = n0 + chunk * 8 < DC;
+            const char* src = ok ? a.nx + ((((size_t)img * a.H + h0 + (p >> 7)) * a.W + w0 + (p & 127)) * DC + n0 + chunk * 8) * 2 : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lH + id * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int dc = n0 + wn * WN + i * 16 + fq * 4;
@@ -1051,7 +1067,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
                 for (int e = 0; e < 4; ++e) { const float vr = (float)pk[e]; s1[e] += vr; s2[e] += vr * vr; }
             }
             if (STATS == 2) {
-                const bf16x4 xq = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(a.nx) + dpix * DC + dc);
+                const int pl = wm * 128 + j * 16 + frow, cl = wn * WN + i * 16 + fq * 4;      // tile pixel, tile channel
+                const bf16x4 xq = *reinterpret_cast<const bf16x4*>(smem + (size_t)pl * 512 + (((cl >> 3) ^ (pl & 31)) << 4) + (cl & 7) * 2);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float xh = ((float)xq[e] - mu[e]) * rs[e];

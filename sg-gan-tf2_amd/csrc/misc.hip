@@ -74,17 +74,27 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const char* dy, flo
         __syncthreads();
     }
 }
-// one block per 64 channels; 4 chunk-lanes per channel combined in fixed order
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, float* out, int C, int Cr, int chunks, int accumulate) {
-    __shared__ double red[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
+// one 1024-thread block per 16 channels; 64 chunk-lanes per channel, four independent loads in flight each, combined in
+// fixed order (the head's bias gradient has 1 024 chunks of 8 channels: 4 lanes walking them one dependent load after
+// the other took 25 us)
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* partial, float* out, int C, int Cr, int chunks, int accumulate) {
+    __shared__ double red[64][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tx;
     double s = 0.0;
-    if (c < C) for (int k = ty; k < chunks; k += 4) s += (double)partial[(size_t)k * C + c];
+    if (c < C)
+        for (int k0 = ty; k0 < chunks; k0 += 64 * 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int k = k0 + 64 * u; v[u] = k < chunks ? partial[(size_t)k * C + c] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += (double)v[u];
+        }
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && c < Cr) {
-        s = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+        s = 0.0;
+        for (int l = 0; l < 64; ++l) s += red[l][tx];
         out[c] = accumulate ? out[c] + (float)s : (float)s;
     }
 }
@@ -446,7 +456,7 @@ int sgg_bias_grad(const void* dy, float* db, int64_t P, int C, int C_real, int a
     if (dtype == SGG_BF16) hipLaunchKernelGGL(colsum_partial_kernel<bf16>, dim3(chunks), dim3(256), 0, s, (const char*)dy, (float*)ws, P, C);
     else if (dtype == SGG_F32) hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(chunks), dim3(256), 0, s, (const char*)dy, (float*)ws, P, C);
     else return SGG_EINVAL;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, (const float*)ws, db, C, C_real, chunks, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, (const float*)ws, db, C, C_real, chunks, accumulate);
     return sgg_check_launch();
 }
 

@@ -101,18 +101,26 @@ __global__ __launch_bounds__(256) void in_partial_kernel(const char* x, const ch
     }
 }
 
-// Finalize: one block per (64 channels, image); 4 chunk-lanes per channel, combined in fixed order (deterministic).
+// Finalize: one 1024-thread block per (32 channels, image); 32 chunk-lanes per channel, each with up to four independent
+// loads in flight, combined in fixed order (deterministic).  (8 lanes walking 16 chunks one dependent L2 load after the
+// other took 5-6 us per launch -- 250 launches per cycle step, 3.7 % of it.)
 #define FIN_CH 32
-#define FIN_LANES 8
+#define FIN_LANES 32
 __device__ inline void fin_reduce(const float* partial, int n, int c, int chunks, int C, int lane, double& s1, double& s2) {
     s1 = 0.0; s2 = 0.0;
-    for (int k = lane; k < chunks; k += FIN_LANES) {
-        size_t o = (((size_t)n * chunks + k) * C + c) * 2;
-        s1 += (double)partial[o]; s2 += (double)partial[o + 1];
+    for (int k0 = lane; k0 < chunks; k0 += FIN_LANES * 4) {
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * FIN_LANES;
+            v[u] = k < chunks ? *reinterpret_cast<const float2*>(partial + (((size_t)n * chunks + k) * C + c) * 2) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
     }
 }
 
-__global__ __launch_bounds__(256) void in_finalize_fwd_kernel(const float* partial, float* stats, int64_t HW, int C, int chunks, float eps) {
+__global__ __launch_bounds__(1024) void in_finalize_fwd_kernel(const float* partial, float* stats, int64_t HW, int C, int chunks, float eps) {
     __shared__ double red[FIN_LANES][FIN_CH][2];
     const int tx = threadIdx.x % FIN_CH, ty = threadIdx.x / FIN_CH;
     const int c = blockIdx.x * FIN_CH + tx, n = blockIdx.y;
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256) void in_finalize_fwd_kernel(const float* parti
 }
 
 // sums[n][c] = (sum g, sum g*xhat) / HW ; tot[n][c] = the raw sums (for dgamma/dbeta)
-__global__ __launch_bounds__(256) void in_finalize_bwd_kernel(const float* partial, float* sums, float* tot, int64_t HW, int C, int chunks) {
+__global__ __launch_bounds__(1024) void in_finalize_bwd_kernel(const float* partial, float* sums, float* tot, int64_t HW, int C, int chunks) {
     __shared__ double red[FIN_LANES][FIN_CH][2];
     const int tx = threadIdx.x % FIN_CH, ty = threadIdx.x / FIN_CH;
     const int c = blockIdx.x * FIN_CH + tx, n = blockIdx.y;
@@ -369,11 +377,11 @@ int sgg_instnorm_fwd(const void* x, const float* gamma, const float* beta, const
     dim3 gp(chunks, N), ga((unsigned)((HW + rpb - 1) / rpb), N);
     if (dtype == SGG_BF16) {
         hipLaunchKernelGGL((in_partial_kernel<bf16, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
-        hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, stats, HW, C, chunks, eps);
+        hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, stats, HW, C, chunks, eps);
         hipLaunchKernelGGL((in_apply_kernel<bf16, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{});
     } else if (dtype == SGG_F32) {
         hipLaunchKernelGGL((in_partial_kernel<float, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
-        hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, stats, HW, C, chunks, eps);
+        hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, stats, HW, C, chunks, eps);
         hipLaunchKernelGGL((in_apply_kernel<float, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{});
     } else return SGG_EINVAL;
     return sgg_check_launch();
@@ -388,7 +396,7 @@ int sgg_instnorm_fwd_partial(const void* x, const float* gamma, const float* bet
     hipStream_t s = (hipStream_t)stream;
     int rpb = in_rows_per_block(N, HW, C, 0);
     dim3 ga((unsigned)((HW + rpb - 1) / rpb), N);
-    hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, stats, HW, C, chunks, eps);
+    hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, stats, HW, C, chunks, eps);
     if (dtype == SGG_BF16) hipLaunchKernelGGL((in_apply_kernel<bf16, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{});
     else hipLaunchKernelGGL((in_apply_kernel<float, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{});
     return sgg_check_launch();
@@ -419,11 +427,11 @@ int sgg_instnorm_bwd(const void* dy, const void* x, const float* gamma, const fl
     }
     if (dtype == SGG_BF16) {
         hipLaunchKernelGGL((in_partial_kernel<bf16, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
-        hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, sums, tot, HW, C, chunks);
+        hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, sums, tot, HW, C, chunks);
         hipLaunchKernelGGL((in_apply_kernel<bf16, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg);
     } else if (dtype == SGG_F32) {
         hipLaunchKernelGGL((in_partial_kernel<float, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
-        hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, sums, tot, HW, C, chunks);
+        hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, sums, tot, HW, C, chunks);
         hipLaunchKernelGGL((in_apply_kernel<float, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg);
     } else return SGG_EINVAL;
     return sgg_check_launch();
@@ -447,7 +455,7 @@ int sgg_instnorm_bwd_mixed(const float* dy, const void* x, const float* gamma, c
     dim3 gp(chunks, N), ga((unsigned)((HW + rpb - 1) / rpb), N);
     const InParamGrad pg{tot, dgamma, dbeta, N, C_real, accumulate};
     hipLaunchKernelGGL((in_partial_kernel<bf16, true, float>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
-    hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, sums, tot, HW, C, chunks);
+    hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, sums, tot, HW, C, chunks);
     hipLaunchKernelGGL((in_apply_kernel<bf16, true, float>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg);
     return sgg_check_launch();
 }
@@ -466,7 +474,7 @@ int sgg_instnorm_bwd_partial(const void* dy, const void* x, const float* gamma, 
     int rpb = in_rows_per_block(N, HW, C, 0);
     dim3 ga((unsigned)((HW + rpb - 1) / rpb), N);
     const InParamGrad pg{tot, dgamma, dbeta, N, C_real, accumulate};
-    hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(256), 0, s, partial, sums, tot, HW, C, chunks);
+    hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, sums, tot, HW, C, chunks);
     if (dtype == SGG_BF16) hipLaunchKernelGGL((in_apply_kernel<bf16, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg);
     else hipLaunchKernelGGL((in_apply_kernel<float, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg);
     return sgg_check_launch();

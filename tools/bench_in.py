@@ -23,6 +23,7 @@ def timeit(f, iters=30):
 SHAPES = ((8, 64, 128, 256), (8, 128, 256, 128), (8, 256, 512, 64), (8, 32, 64, 256), (8, 5, 13, 512))
 if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "res":
     SHAPES = SHAPES[:1]                       # the residual-block tensor only (PMC passes: tools/pmc_in.sh)
+DIR = sys.argv[sys.argv.index("--dir") + 1] if "--dir" in sys.argv else "both"
 for shape in SHAPES:
     x = torch.randn(shape, device="cuda").to(torch.bfloat16)
     dy = torch.randn(shape, device="cuda").to(torch.bfloat16)
@@ -31,6 +32,6 @@ for shape in SHAPES:
     dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
     y, st = K.instnorm_fwd(x, g, b, None, 1e-3, A.ACT_RELU)
     by = x.numel() * 2
-    tf = timeit(lambda: K.instnorm_fwd(x, g, b, None, 1e-3, A.ACT_RELU))
-    tb = timeit(lambda: K.instnorm_bwd(dy, x, g, b, st, dg, db, False, A.ACT_RELU))
+    tf = timeit(lambda: K.instnorm_fwd(x, g, b, None, 1e-3, A.ACT_RELU)) if DIR in ("both", "fwd") else float("nan")
+    tb = timeit(lambda: K.instnorm_bwd(dy, x, g, b, st, dg, db, False, A.ACT_RELU)) if DIR in ("both", "bwd") else float("nan")
     print(f"{str(shape):22s} {by/1e6:7.1f} MB | fwd {tf:7.1f} us {3*by/tf/1e3:7.0f} GB/s | bwd {tb:7.1f} us {5*by/tb/1e3:7.0f} GB/s", flush=True)

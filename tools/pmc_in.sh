@@ -6,19 +6,21 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/pmc_in
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$c -- python3 $R/tools/bench_in.py --only res > $O/$c.log 2>&1 || echo "pass $c failed"
+for dir in fwd bwd; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${dir}_$c -- python3 $R/tools/bench_in.py --only res --dir $dir > $O/${dir}_$c.log 2>&1 || echo "pass $dir $c failed"
+  done
 done
 python3 - <<PY > $O/in_traffic.json
 import csv, glob, json, collections
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$O/**/*counter_collection.csv", recursive=True):
+    d = "bwd" if "/bwd_" in f else "fwd"             # one direction per pass (tools/bench_in.py --dir)
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         for key in ("in_apply_kernel", "in_partial_kernel", "in_finalize"):
             if key in n:
-                bwd = ("true" in n.split("<")[-1]) if "<" in n else ("Lb1" in n)
-                vals[key + ("_bwd" if bwd else "_fwd")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                vals[key + "_" + d][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, m in sorted(vals.items()):
     mean = {c: sum(v) / len(v) for c, v in m.items()}

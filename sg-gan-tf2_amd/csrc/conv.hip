@@ -2795,26 +2795,40 @@ __global__ void pack_weights_kernel(const float* w, int taps, int C, int K, int 
 // every conv layer of a network in ONE launch (blockIdx.y = layer): after each optimizer step all packed weights are stale,
 // and 16 separate 8-us launches per network were pure launch latency
 template <typename T>
-__global__ void pack_weights_batch_kernel(const sgg_pack_item* items) {
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(const sgg_pack_item* items) {
+    // (tap, 64 c, 64 k) tiles: w[tap][c][k] is read along k, w_dgrad[c][tap][k] written along k, and w_fwd[k][tap][c] -- the
+    // transposed layout -- written along c out of an LDS tile.  (One thread per element wrote w_fwd as 2-byte scatters, one
+    // cache line per lane: 83 us for a generator's 11.4 M parameters, 1.1 TB/s.)
+    __shared__ float tile[64][65];
     const sgg_pack_item it = items[blockIdx.y];
     const int taps = it.taps, C = it.C, K = it.K, Cpad = it.Cpad, Kpad = it.Kpad;
     const float* w = it.w;
     T* wf = (T*)it.w_fwd;
     T* wd = (T*)it.w_dgrad;
-    int64_t total = (int64_t)taps * Cpad * Kpad;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int k = (int)(i % Kpad);
-        int64_t t = i / Kpad;
-        int c = (int)(t % Cpad), tap = (int)(t / Cpad);
-        float v = (c < C && k < K) ? w[((size_t)tap * C + c) * K + k] : 0.f;
-        if (wf) wf[((size_t)k * taps + tap) * Cpad + c] = (T)v;
-        if (wd) wd[((size_t)c * taps + tap) * Kpad + k] = (T)v;
+    const int tc = (Cpad + 63) / 64, tk = (Kpad + 63) / 64;
+    const int ntiles = taps * tc * tk;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int kt = t % tk, ct = (t / tk) % tc, tap = t / (tk * tc);
+        const int k = kt * 64 + lx;
+        for (int cy = ly; cy < 64; cy += 4) {
+            const int c = ct * 64 + cy;
+            const float v = (c < C && k < K) ? w[((size_t)tap * C + c) * K + k] : 0.f;
+            tile[cy][lx] = v;
+            if (wd && c < Cpad && k < Kpad) wd[((size_t)c * taps + tap) * Kpad + k] = (T)v;
+        }
+        __syncthreads();
+        if (wf) {
+            const int c = ct * 64 + lx;
+            for (int ky = ly; ky < 64; ky += 4) {
+                const int kk = kt * 64 + ky;
+                if (c < Cpad && kk < Kpad) wf[((size_t)kk * taps + tap) * Cpad + c] = (T)tile[lx][ky];
+            }
+        }
+        __syncthreads();
     }
 }
 
-// -------------------------------------------------------------------------------------------------
-// host side
-// -------------------------------------------------------------------------------------------------
 static bool desc_ok(const sgg_conv_desc* d) {
     if (!d) return false;
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->R <= 0 || d->S <= 0) return false;
@@ -3543,7 +3557,7 @@ int sgg_pack_conv_weights(const float* w, int R, int S, int C, int K, int Cpad, 
 
 int sgg_pack_conv_weights_batch(const sgg_pack_item* items_dev, int n_items, int64_t max_elems, int dtype, void* stream) {
     if (!items_dev || n_items <= 0 || max_elems <= 0) return SGG_EINVAL;
-    int blocks = (int)((max_elems + 255) / 256); if (blocks > 1024) blocks = 1024;
+    int blocks = (int)((max_elems + 4095) / 4096); if (blocks > 1024) blocks = 1024;     // 64 x 64 tiles, grid-strided
     dim3 grid((unsigned)blocks, (unsigned)n_items);
     if (dtype == SGG_BF16) hipLaunchKernelGGL(pack_weights_batch_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, items_dev);
     else if (dtype == SGG_F32) hipLaunchKernelGGL(pack_weights_batch_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, items_dev);

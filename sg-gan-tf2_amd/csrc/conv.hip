@@ -704,8 +704,11 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
 // -------------------------------------------------------------------------------------------------
 #define H3_TW 128
 #ifndef H3_ISSUER_HALF
-#define H3_ISSUER_HALF 1                               // which half of the waves (0: waves 0-3, 1: waves 4-7) issues the main loop's DMAs
+#define H3_ISSUER_HALF 1                               // which half of the waves (0: waves 0-3, 1: waves 4-7) issues the main loop's weight DMAs
 #endif
+#ifndef H3_HALO_HALF
+#define H3_HALO_HALF 1                                 // ... and which half the halo-row DMAs (the other half measured 3-6 % slower:
+#endif                                                 //     the non-issuers' early MFMAs are what covers the issuers' DMA phase)
 #define H3_PITCH 136                                   // halo row pitch in pixels (130 used; multiple of 8 = one DMA)
 #define H3_HALO_BYTES (4 * H3_PITCH * 128)
 #define H3_PATCH_ROWS 40                               // 2 tile rows x 2 sides x 9 taps = 36, rounded to whole DMAs
@@ -867,17 +870,21 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         // (tools/halo_phases.py).  Now waves 4-7 issue ALL the DMAs while waves 0-3 -- their SIMD partners -- go straight to
         // their MFMAs.  (Not the same as splitting each wave's issue in time: waves 4-7 issuing their own share half way
         // through the tile measured 7 % slower.)
-        if ((abl == 0 || abl == 2) && (wave >> 2) == H3_ISSUER_HALF) {
+        if (abl == 0 || abl == 2) {
             const int vw = wave & 3;
-            int ntap = tap + 1, nchk = chunk;
-            if (ntap == 9) { ntap = 0; ++nchk; }
-            if (t + 1 < ntiles) load_w((t + 1) & 1, nchk, MODE == MODE_FWD ? ntap : 8 - ntap, vw, 4);
-            if (tap == 0 && chunk > 0) load_halo_row(2, chunk, vw, 4);
-            if (tap == 3) {
-                if (chunk > 0) load_halo_row(3, chunk, vw, 4);
-                if (chunk + 1 < nchunk) { load_halo_row(0, chunk + 1, vw, 4); load_patch(chunk + 1, vw, 4); }
+            if ((wave >> 2) == H3_ISSUER_HALF) {           // the weight tile: 8 DMA instructions per issuer wave and tile
+                int ntap = tap + 1, nchk = chunk;
+                if (ntap == 9) { ntap = 0; ++nchk; }
+                if (t + 1 < ntiles) load_w((t + 1) & 1, nchk, MODE == MODE_FWD ? ntap : 8 - ntap, vw, 4);
             }
-            if (tap == 6 && chunk + 1 < nchunk) load_halo_row(1, chunk + 1, vw, 4);
+            if ((wave >> 2) == H3_HALO_HALF) {             // the halo rows (17 instructions each, ~1 row per tile on average)
+                if (tap == 0 && chunk > 0) load_halo_row(2, chunk, vw, 4);
+                if (tap == 3) {
+                    if (chunk > 0) load_halo_row(3, chunk, vw, 4);
+                    if (chunk + 1 < nchunk) { load_halo_row(0, chunk + 1, vw, 4); load_patch(chunk + 1, vw, 4); }
+                }
+                if (tap == 6 && chunk + 1 < nchunk) load_halo_row(1, chunk + 1, vw, 4);
+            }
         }
         H3_STAMP(1);
         const int r = tap / 3, sx = tap - 3 * r;

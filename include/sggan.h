@@ -175,6 +175,22 @@ int sgg_instnorm_bwd_partial(const void* dy, const void* x, const float* gamma, 
                              float* dgamma, float* dbeta, const float* partial, int chunks, int N, int64_t HW, int C, int C_real,
                              int accumulate, int act, float leak, int dtype, void* ws, size_t ws_bytes, void* stream);
 
+/* Two networks of the same shape in lockstep on ONE stacked batch (the cycle step's G_A->B / G_B->A and D_A / D_B pairs,
+ * model.py:114-133 applied to both translation directions): images 0..nsplit-1 belong to the first network (gamma, beta,
+ * dgamma, dbeta), images nsplit..N-1 to the second (gamma2, ...).  Instance norm is per image, so one launch over the 2x larger
+ * tensor serves both -- same arithmetic per image as two separate calls (bit-identical), at a higher fraction of HBM bandwidth
+ * and half the launches. */
+int sgg_instnorm_fwd_pair(const void* x, const float* gamma, const float* beta, const float* gamma2, const float* beta2, int nsplit,
+                          const void* residual, void* y, float* stats, int N, int64_t HW, int C, float eps, int act, float leak,
+                          int dtype, void* ws, size_t ws_bytes, void* stream);
+int sgg_instnorm_fwd_partial_pair(const void* x, const float* gamma, const float* beta, const float* gamma2, const float* beta2, int nsplit,
+                                  const void* residual, void* y, float* stats, const float* partial, int chunks, int N, int64_t HW, int C,
+                                  float eps, int act, float leak, int dtype, void* stream);
+int sgg_instnorm_bwd_pair(const void* dy, const void* x, const float* gamma, const float* beta, const float* gamma2, const float* beta2,
+                          int nsplit, const float* stats, void* dx, float* dgamma, float* dbeta, float* dgamma2, float* dbeta2,
+                          int N, int64_t HW, int C, int C_real, int accumulate, int act, float leak, int dtype,
+                          void* ws, size_t ws_bytes, void* stream);
+
 /* ---- lrelu / relu / tanh: tf.keras.layers.LeakyReLU / Activation ---- module.py:213,265,285 (ops.py:36-37) */
 int sgg_act_fwd(const void* x, void* y, int64_t n, int act, float leak, int dtype, void* stream);
 /* dx = dy * act'(.) evaluated from the OUTPUT y (relu/lrelu: sign of y; tanh: 1-y^2). */

@@ -64,6 +64,9 @@ SIGNATURES = {
     "sgg_instnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _i, _f, _i, _vp, _sz, _vp]),
     "sgg_instnorm_fwd_partial": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _f, _i, _f, _i, _vp]),
     "sgg_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
+    "sgg_instnorm_fwd_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _f, _i, _f, _i, _vp, _sz, _vp]),
+    "sgg_instnorm_fwd_partial_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _f, _i, _f, _i, _vp]),
+    "sgg_instnorm_bwd_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "sgg_instnorm_bwd_mixed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "sgg_instnorm_bwd_partial": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "sgg_act_fwd": (_i, [_vp, _vp, _i64, _i, _f, _i, _vp]),

@@ -15,6 +15,12 @@
 // visible against the float64 oracle (tools/diag_d_f32.py).  On the bf16 path the operands carry 8 bits: f32 is plenty.
 template <typename T> using InAcc = typename std::conditional<std::is_same<T, float>::value, double, float>::type;
 
+// Two networks of the same shape run in lockstep on a batch that stacks their activations (images 0..nsplit-1 belong to
+// the first, the rest to the second -- the cycle step's G_A->B / G_B->A and D_A / D_B pairs): the norm is per image, so one
+// launch serves both and only the affine parameters (and their gradients) are picked by image index.  nsplit >= N: one network.
+struct InSplit { const float* gamma2; const float* beta2; float* dgamma2; float* dbeta2; int nsplit; };
+static inline InSplit in_nosplit() { InSplit s; s.gamma2 = nullptr; s.beta2 = nullptr; s.dgamma2 = nullptr; s.dbeta2 = nullptr; s.nsplit = 0x7fffffff; return s; }
+
 // The incoming gradient dy normally has the tensor's storage type T.  Mixed mode (bf16 tensors, f32 gradient chain): dy is
 // f32 -- the VEC channels of a 16-byte chunk of x are then two 16-byte chunks of dy.  `elem` = element index of the chunk.
 template <typename T, typename TG>
@@ -41,10 +47,11 @@ static inline int in_chunks(int64_t HW) { int r = in_rows_per_chunk(HW); return 
 template <typename T, bool BWD, typename TG = T>
 __global__ __launch_bounds__(256) void in_partial_kernel(const char* x, const char* dy, const float* gamma, const float* beta,
                                                          const float* stats, float* partial, int64_t HW, int C, int chunks,
-                                                         int rpc, int act, float leak) {
+                                                         int rpc, int act, float leak, InSplit sp) {
     constexpr int VEC = ET<T>::VEC;
     const int CV = C / VEC;                       // channel vectors per pixel
     const int n = blockIdx.y, chunk = blockIdx.x;
+    if (n >= sp.nsplit) { gamma = sp.gamma2; beta = sp.beta2; }
     const int64_t p0 = (int64_t)chunk * rpc;
     const int64_t p1 = p0 + rpc < HW ? p0 + rpc : HW;
     using AccT = InAcc<T>;
@@ -158,23 +165,31 @@ __global__ __launch_bounds__(1024) void in_finalize_bwd_kernel(const float* part
 // dgamma[c] (+)= sum_n sum g*xhat ; dbeta[c] (+)= sum_n sum g   (fixed order over n -> deterministic).  Run by the
 // first block of the backward apply kernel (a separate launch cost ~5 us per instance norm for a few hundred FLOPs).
 struct InParamGrad { const float* tot; float* dgamma; float* dbeta; int N, Cr, accumulate; };
-__device__ inline void in_param_grad(const InParamGrad& g, int C) {
+__device__ inline void in_param_grad(const InParamGrad& g, int C, const InSplit& sp) {
+    const int n1 = g.N < sp.nsplit ? g.N : sp.nsplit;
     for (int c = threadIdx.x; c < g.Cr; c += blockDim.x) {
         double tg = 0.0, tb = 0.0;
-        for (int n = 0; n < g.N; ++n) { tb += (double)g.tot[((size_t)n * C + c) * 2]; tg += (double)g.tot[((size_t)n * C + c) * 2 + 1]; }
+        for (int n = 0; n < n1; ++n) { tb += (double)g.tot[((size_t)n * C + c) * 2]; tg += (double)g.tot[((size_t)n * C + c) * 2 + 1]; }
         g.dgamma[c] = g.accumulate ? g.dgamma[c] + (float)tg : (float)tg;
         g.dbeta[c] = g.accumulate ? g.dbeta[c] + (float)tb : (float)tb;
+        if (n1 < g.N) {                                  // the second network's images
+            tg = 0.0; tb = 0.0;
+            for (int n = n1; n < g.N; ++n) { tb += (double)g.tot[((size_t)n * C + c) * 2]; tg += (double)g.tot[((size_t)n * C + c) * 2 + 1]; }
+            sp.dgamma2[c] = g.accumulate ? sp.dgamma2[c] + (float)tg : (float)tg;
+            sp.dbeta2[c] = g.accumulate ? sp.dbeta2[c] + (float)tb : (float)tb;
+        }
     }
 }
 
 template <typename T, bool BWD, typename TG = T>
 __global__ __launch_bounds__(256) void in_apply_kernel(const char* x, const char* dy, const char* residual, const float* gamma,
                                                        const float* beta, const float* stats, const float* sums, char* out,
-                                                       int64_t HW, int C, int rows_per_block, int act, float leak, InParamGrad pg) {
+                                                       int64_t HW, int C, int rows_per_block, int act, float leak, InParamGrad pg, InSplit sp) {
     constexpr int VEC = ET<T>::VEC;
     const int CV = C / VEC;
     const int n = blockIdx.y;
-    if (BWD && blockIdx.x == 0 && blockIdx.y == 0) in_param_grad(pg, C);
+    if (BWD && blockIdx.x == 0 && blockIdx.y == 0) in_param_grad(pg, C, sp);
+    if (n >= sp.nsplit) { gamma = sp.gamma2; beta = sp.beta2; }
     const int64_t p0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t p1 = p0 + rows_per_block < HW ? p0 + rows_per_block : HW;
     for (int cvb = 0; cvb < CV; cvb += 256) {
@@ -233,11 +248,12 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const char* x, const char
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void in_fused_small_kernel(const char* x, const char* dy, const char* residual, const float* gamma,
                                                              const float* beta, float* stats, float* tot, char* out,
-                                                             int64_t HW, int C, float eps, int act, float leak) {
+                                                             int64_t HW, int C, float eps, int act, float leak, InSplit sp) {
     constexpr int VEC = ET<T>::VEC;
     constexpr int ROWS = 256 / IN_CVB;
     const int CV = C / VEC;
     const int n = blockIdx.y;
+    if (n >= sp.nsplit) { gamma = sp.gamma2; beta = sp.beta2; }
     const int cvl = threadIdx.x % IN_CVB, prow = threadIdx.x / IN_CVB;
     const int cv = blockIdx.x * IN_CVB + cvl;
     const bool live = cv < CV;
@@ -335,7 +351,7 @@ __global__ __launch_bounds__(256) void in_fused_small_kernel(const char* x, cons
     }
 }
 
-__global__ void in_param_grad_kernel(InParamGrad g, int C) { in_param_grad(g, C); }
+__global__ void in_param_grad_kernel(InParamGrad g, int C, InSplit sp) { in_param_grad(g, C, sp); }
 
 static bool in_use_fused(int64_t HW) {
     const int mx = sgg_config().in_fused_maxhw;
@@ -357,8 +373,8 @@ size_t sgg_instnorm_workspace(int N, int64_t HW, int C) {
     return ((size_t)N * in_chunks(HW) * C * 2 + (size_t)N * C * 4) * sizeof(float);
 }
 
-int sgg_instnorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* stats,
-                     int N, int64_t HW, int C, float eps, int act, float leak, int dtype, void* ws, size_t ws_bytes, void* stream) {
+static int instnorm_fwd_impl(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* stats,
+                     int N, int64_t HW, int C, float eps, int act, float leak, int dtype, void* ws, size_t ws_bytes, void* stream, InSplit sp) {
     if (!x || !gamma || !beta || !y || !stats || N <= 0 || HW <= 0 || C <= 0 || C % SGG_CPAD) return SGG_EINVAL;
     if (act == SGG_ACT_TANH) return SGG_EUNSUPPORTED;
     if (!ws || ws_bytes < sgg_instnorm_workspace(N, HW, C)) return SGG_EWORKSPACE;
@@ -367,8 +383,8 @@ int sgg_instnorm_fwd(const void* x, const float* gamma, const float* beta, const
     if (in_use_fused(HW)) {
         const int vec = dtype == SGG_BF16 ? 8 : 4;
         dim3 gf((unsigned)((C / vec + IN_CVB - 1) / IN_CVB), N);
-        if (dtype == SGG_BF16) hipLaunchKernelGGL((in_fused_small_kernel<bf16, false>), gf, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, eps, act, leak);
-        else hipLaunchKernelGGL((in_fused_small_kernel<float, false>), gf, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, eps, act, leak);
+        if (dtype == SGG_BF16) hipLaunchKernelGGL((in_fused_small_kernel<bf16, false>), gf, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, eps, act, leak, sp);
+        else hipLaunchKernelGGL((in_fused_small_kernel<float, false>), gf, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, eps, act, leak, sp);
         return sgg_check_launch();
     }
     int chunks = in_chunks(HW);
@@ -376,20 +392,20 @@ int sgg_instnorm_fwd(const void* x, const float* gamma, const float* beta, const
     int rpb = in_rows_per_block(N, HW, C, 0);
     dim3 gp(chunks, N), ga((unsigned)((HW + rpb - 1) / rpb), N);
     if (dtype == SGG_BF16) {
-        hipLaunchKernelGGL((in_partial_kernel<bf16, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
+        hipLaunchKernelGGL((in_partial_kernel<bf16, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak, sp);
         hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, stats, HW, C, chunks, eps);
-        hipLaunchKernelGGL((in_apply_kernel<bf16, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{});
+        hipLaunchKernelGGL((in_apply_kernel<bf16, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{}, sp);
     } else if (dtype == SGG_F32) {
-        hipLaunchKernelGGL((in_partial_kernel<float, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
+        hipLaunchKernelGGL((in_partial_kernel<float, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak, sp);
         hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, stats, HW, C, chunks, eps);
-        hipLaunchKernelGGL((in_apply_kernel<float, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{});
+        hipLaunchKernelGGL((in_apply_kernel<float, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{}, sp);
     } else return SGG_EINVAL;
     return sgg_check_launch();
 }
 
-int sgg_instnorm_fwd_partial(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* stats,
+static int instnorm_fwd_partial_impl(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* stats,
                              const float* partial, int chunks, int N, int64_t HW, int C, float eps, int act, float leak, int dtype,
-                             void* stream) {
+                             void* stream, InSplit sp) {
     if (!x || !gamma || !beta || !y || !stats || !partial || chunks <= 0 || N <= 0 || HW <= 0 || C <= 0 || C % SGG_CPAD) return SGG_EINVAL;
     if (act == SGG_ACT_TANH) return SGG_EUNSUPPORTED;
     if (dtype != SGG_BF16 && dtype != SGG_F32) return SGG_EINVAL;
@@ -397,14 +413,14 @@ int sgg_instnorm_fwd_partial(const void* x, const float* gamma, const float* bet
     int rpb = in_rows_per_block(N, HW, C, 0);
     dim3 ga((unsigned)((HW + rpb - 1) / rpb), N);
     hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, stats, HW, C, chunks, eps);
-    if (dtype == SGG_BF16) hipLaunchKernelGGL((in_apply_kernel<bf16, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{});
-    else hipLaunchKernelGGL((in_apply_kernel<float, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{});
+    if (dtype == SGG_BF16) hipLaunchKernelGGL((in_apply_kernel<bf16, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{}, sp);
+    else hipLaunchKernelGGL((in_apply_kernel<float, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{}, sp);
     return sgg_check_launch();
 }
 
-int sgg_instnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
+static int instnorm_bwd_impl(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
                      float* dgamma, float* dbeta, int N, int64_t HW, int C, int C_real, int accumulate, int act, float leak,
-                     int dtype, void* ws, size_t ws_bytes, void* stream) {
+                     int dtype, void* ws, size_t ws_bytes, void* stream, InSplit sp) {
     if (!dy || !x || !gamma || !beta || !stats || !dx || !dgamma || !dbeta || N <= 0 || HW <= 0 || C <= 0 || C % SGG_CPAD || C_real <= 0 || C_real > C) return SGG_EINVAL;
     if (act == SGG_ACT_TANH) return SGG_EUNSUPPORTED;
     if (!ws || ws_bytes < sgg_instnorm_workspace(N, HW, C)) return SGG_EWORKSPACE;
@@ -420,19 +436,19 @@ int sgg_instnorm_bwd(const void* dy, const void* x, const float* gamma, const fl
     if (in_use_fused(HW)) {
         const int vec = dtype == SGG_BF16 ? 8 : 4;
         dim3 gf((unsigned)((C / vec + IN_CVB - 1) / IN_CVB), N);
-        if (dtype == SGG_BF16) hipLaunchKernelGGL((in_fused_small_kernel<bf16, true>), gf, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, (float*)stats, tot, (char*)dx, HW, C, 0.f, act, leak);
-        else hipLaunchKernelGGL((in_fused_small_kernel<float, true>), gf, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, (float*)stats, tot, (char*)dx, HW, C, 0.f, act, leak);
-        hipLaunchKernelGGL(in_param_grad_kernel, dim3(1), dim3(256), 0, s, pg, C);
+        if (dtype == SGG_BF16) hipLaunchKernelGGL((in_fused_small_kernel<bf16, true>), gf, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, (float*)stats, tot, (char*)dx, HW, C, 0.f, act, leak, sp);
+        else hipLaunchKernelGGL((in_fused_small_kernel<float, true>), gf, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, (float*)stats, tot, (char*)dx, HW, C, 0.f, act, leak, sp);
+        hipLaunchKernelGGL(in_param_grad_kernel, dim3(1), dim3(256), 0, s, pg, C, sp);
         return sgg_check_launch();
     }
     if (dtype == SGG_BF16) {
-        hipLaunchKernelGGL((in_partial_kernel<bf16, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
+        hipLaunchKernelGGL((in_partial_kernel<bf16, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak, sp);
         hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, sums, tot, HW, C, chunks);
-        hipLaunchKernelGGL((in_apply_kernel<bf16, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg);
+        hipLaunchKernelGGL((in_apply_kernel<bf16, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg, sp);
     } else if (dtype == SGG_F32) {
-        hipLaunchKernelGGL((in_partial_kernel<float, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
+        hipLaunchKernelGGL((in_partial_kernel<float, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak, sp);
         hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, sums, tot, HW, C, chunks);
-        hipLaunchKernelGGL((in_apply_kernel<float, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg);
+        hipLaunchKernelGGL((in_apply_kernel<float, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg, sp);
     } else return SGG_EINVAL;
     return sgg_check_launch();
 }
@@ -440,9 +456,9 @@ int sgg_instnorm_bwd(const void* dy, const void* x, const float* gamma, const fl
 // Mixed mode: dy is f32, x / dx are bf16 (the gradient chain between the instance norms of the residual blocks stays f32:
 // the norm backward subtracts the mean and the xhat-correlated part of dy, so a bf16 rounding of dy -- relative to dy, not
 // to what is left of it -- is amplified there layer after layer).  Same passes as sgg_instnorm_bwd.
-int sgg_instnorm_bwd_mixed(const float* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
+static int instnorm_bwd_mixed_impl(const float* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
                            float* dgamma, float* dbeta, int N, int64_t HW, int C, int C_real, int accumulate, int act, float leak,
-                           void* ws, size_t ws_bytes, void* stream) {
+                           void* ws, size_t ws_bytes, void* stream, InSplit sp) {
     if (!dy || !x || !gamma || !beta || !stats || !dx || !dgamma || !dbeta || N <= 0 || HW <= 0 || C <= 0 || C % SGG_CPAD || C_real <= 0 || C_real > C) return SGG_EINVAL;
     if (act == SGG_ACT_TANH) return SGG_EUNSUPPORTED;
     if (!ws || ws_bytes < sgg_instnorm_workspace(N, HW, C)) return SGG_EWORKSPACE;
@@ -454,15 +470,15 @@ int sgg_instnorm_bwd_mixed(const float* dy, const void* x, const float* gamma, c
     int rpb = in_rows_per_block(N, HW, C, 0);
     dim3 gp(chunks, N), ga((unsigned)((HW + rpb - 1) / rpb), N);
     const InParamGrad pg{tot, dgamma, dbeta, N, C_real, accumulate};
-    hipLaunchKernelGGL((in_partial_kernel<bf16, true, float>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak);
+    hipLaunchKernelGGL((in_partial_kernel<bf16, true, float>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak, sp);
     hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, sums, tot, HW, C, chunks);
-    hipLaunchKernelGGL((in_apply_kernel<bf16, true, float>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg);
+    hipLaunchKernelGGL((in_apply_kernel<bf16, true, float>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg, sp);
     return sgg_check_launch();
 }
 
-int sgg_instnorm_bwd_partial(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
+static int instnorm_bwd_partial_impl(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
                              float* dgamma, float* dbeta, const float* partial, int chunks, int N, int64_t HW, int C, int C_real,
-                             int accumulate, int act, float leak, int dtype, void* ws, size_t ws_bytes, void* stream) {
+                             int accumulate, int act, float leak, int dtype, void* ws, size_t ws_bytes, void* stream, InSplit sp) {
     if (!dy || !x || !gamma || !beta || !stats || !dx || !dgamma || !dbeta || !partial || chunks <= 0 || N <= 0 || HW <= 0 || C <= 0 ||
         C % SGG_CPAD || C_real <= 0 || C_real > C) return SGG_EINVAL;
     if (act == SGG_ACT_TANH) return SGG_EUNSUPPORTED;
@@ -475,9 +491,59 @@ int sgg_instnorm_bwd_partial(const void* dy, const void* x, const float* gamma, 
     dim3 ga((unsigned)((HW + rpb - 1) / rpb), N);
     const InParamGrad pg{tot, dgamma, dbeta, N, C_real, accumulate};
     hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, sums, tot, HW, C, chunks);
-    if (dtype == SGG_BF16) hipLaunchKernelGGL((in_apply_kernel<bf16, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg);
-    else hipLaunchKernelGGL((in_apply_kernel<float, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg);
+    if (dtype == SGG_BF16) hipLaunchKernelGGL((in_apply_kernel<bf16, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg, sp);
+    else hipLaunchKernelGGL((in_apply_kernel<float, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg, sp);
     return sgg_check_launch();
+}
+
+// ---- public entry points: one network, or two networks of the same shape stacked on the batch dimension ("pair": images
+// 0..nsplit-1 use gamma/beta and add to dgamma/dbeta, the rest use gamma2/beta2 and dgamma2/dbeta2)
+int sgg_instnorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* stats,
+                     int N, int64_t HW, int C, float eps, int act, float leak, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    return instnorm_fwd_impl(x, gamma, beta, residual, y, stats, N, HW, C, eps, act, leak, dtype, ws, ws_bytes, stream, in_nosplit());
+}
+int sgg_instnorm_fwd_partial(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* stats,
+                             const float* partial, int chunks, int N, int64_t HW, int C, float eps, int act, float leak, int dtype,
+                             void* stream) {
+    return instnorm_fwd_partial_impl(x, gamma, beta, residual, y, stats, partial, chunks, N, HW, C, eps, act, leak, dtype, stream, in_nosplit());
+}
+int sgg_instnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
+                     float* dgamma, float* dbeta, int N, int64_t HW, int C, int C_real, int accumulate, int act, float leak,
+                     int dtype, void* ws, size_t ws_bytes, void* stream) {
+    return instnorm_bwd_impl(dy, x, gamma, beta, stats, dx, dgamma, dbeta, N, HW, C, C_real, accumulate, act, leak, dtype, ws, ws_bytes, stream, in_nosplit());
+}
+int sgg_instnorm_bwd_mixed(const float* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
+                           float* dgamma, float* dbeta, int N, int64_t HW, int C, int C_real, int accumulate, int act, float leak,
+                           void* ws, size_t ws_bytes, void* stream) {
+    return instnorm_bwd_mixed_impl(dy, x, gamma, beta, stats, dx, dgamma, dbeta, N, HW, C, C_real, accumulate, act, leak, ws, ws_bytes, stream, in_nosplit());
+}
+int sgg_instnorm_bwd_partial(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
+                             float* dgamma, float* dbeta, const float* partial, int chunks, int N, int64_t HW, int C, int C_real,
+                             int accumulate, int act, float leak, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    return instnorm_bwd_partial_impl(dy, x, gamma, beta, stats, dx, dgamma, dbeta, partial, chunks, N, HW, C, C_real, accumulate, act, leak, dtype, ws, ws_bytes, stream, in_nosplit());
+}
+static inline int in_pair_ok(const float* g2, const float* b2, int nsplit, int N) { return g2 && b2 && nsplit > 0 && nsplit < N; }
+int sgg_instnorm_fwd_pair(const void* x, const float* gamma, const float* beta, const float* gamma2, const float* beta2, int nsplit,
+                          const void* residual, void* y, float* stats, int N, int64_t HW, int C, float eps, int act, float leak,
+                          int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (!in_pair_ok(gamma2, beta2, nsplit, N)) return SGG_EINVAL;
+    InSplit sp = in_nosplit(); sp.gamma2 = gamma2; sp.beta2 = beta2; sp.nsplit = nsplit;
+    return instnorm_fwd_impl(x, gamma, beta, residual, y, stats, N, HW, C, eps, act, leak, dtype, ws, ws_bytes, stream, sp);
+}
+int sgg_instnorm_fwd_partial_pair(const void* x, const float* gamma, const float* beta, const float* gamma2, const float* beta2, int nsplit,
+                                  const void* residual, void* y, float* stats, const float* partial, int chunks, int N, int64_t HW, int C,
+                                  float eps, int act, float leak, int dtype, void* stream) {
+    if (!in_pair_ok(gamma2, beta2, nsplit, N)) return SGG_EINVAL;
+    InSplit sp = in_nosplit(); sp.gamma2 = gamma2; sp.beta2 = beta2; sp.nsplit = nsplit;
+    return instnorm_fwd_partial_impl(x, gamma, beta, residual, y, stats, partial, chunks, N, HW, C, eps, act, leak, dtype, stream, sp);
+}
+int sgg_instnorm_bwd_pair(const void* dy, const void* x, const float* gamma, const float* beta, const float* gamma2, const float* beta2,
+                          int nsplit, const float* stats, void* dx, float* dgamma, float* dbeta, float* dgamma2, float* dbeta2,
+                          int N, int64_t HW, int C, int C_real, int accumulate, int act, float leak, int dtype,
+                          void* ws, size_t ws_bytes, void* stream) {
+    if (!in_pair_ok(gamma2, beta2, nsplit, N) || !dgamma2 || !dbeta2) return SGG_EINVAL;
+    InSplit sp; sp.gamma2 = gamma2; sp.beta2 = beta2; sp.dgamma2 = dgamma2; sp.dbeta2 = dbeta2; sp.nsplit = nsplit;
+    return instnorm_bwd_impl(dy, x, gamma, beta, stats, dx, dgamma, dbeta, N, HW, C, C_real, accumulate, act, leak, dtype, ws, ws_bytes, stream, sp);
 }
 
 }  // extern "C"

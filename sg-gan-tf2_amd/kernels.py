@@ -176,9 +176,17 @@ def repack_batch(table, n, max_elems, dtype):
 
 
 # ----------------------------------------------------------------------------- conv / deconv
-def conv_fwd(g: ConvGeom, x, w_fwd, bias, act=A.ACT_NONE, leak=0.0):
+def _out(out, shape, dtype, device):
+    """The caller's output buffer (a contiguous slice of a stacked pair tensor) or a fresh one."""
+    if out is None:
+        return torch.empty(shape, dtype=dtype, device=device)
+    assert tuple(out.shape) == tuple(shape) and out.dtype == dtype and out.is_contiguous()
+    return out
+
+
+def conv_fwd(g: ConvGeom, x, w_fwd, bias, act=A.ACT_NONE, leak=0.0, out=None):
     assert tuple(x.shape) == g.x_shape and not g.is_deconv, (tuple(x.shape), g.x_shape)
-    y = torch.empty(g.y_shape, dtype=x.dtype, device=x.device)
+    y = _out(out, g.y_shape, x.dtype, x.device)
     pr = _prof("conv2d_fwd", g)
     if pr: pr.start()
     ws = workspace(g.ws_fwd, x.device) if g.ws_fwd else None
@@ -187,11 +195,11 @@ def conv_fwd(g: ConvGeom, x, w_fwd, bias, act=A.ACT_NONE, leak=0.0):
     return y
 
 
-def conv_fwd_stats(g: ConvGeom, x, w_fwd, bias):
+def conv_fwd_stats(g: ConvGeom, x, w_fwd, bias, out=None, out_partial=None):
     """conv forward (no activation) + the per-chunk (sum, sumsq) rows of its output for the instance norm that follows."""
     assert tuple(x.shape) == g.x_shape and not g.is_deconv and g.stats_chunks > 0
-    y = torch.empty(g.y_shape, dtype=x.dtype, device=x.device)
-    partial = torch.empty((g.y_shape[0], g.stats_chunks, g.y_shape[3], 2), dtype=torch.float32, device=x.device)
+    y = _out(out, g.y_shape, x.dtype, x.device)
+    partial = _out(out_partial, (g.y_shape[0], g.stats_chunks, g.y_shape[3], 2), torch.float32, x.device)
     pr = _prof("conv2d_fwd", g)
     if pr: pr.start()
     ws = workspace(g.ws_fwd, x.device) if g.ws_fwd else None
@@ -200,7 +208,7 @@ def conv_fwd_stats(g: ConvGeom, x, w_fwd, bias):
     return y, partial
 
 
-def conv_dgrad(g: ConvGeom, dy, w_dgrad, addend=None, out_f32=False):
+def conv_dgrad(g: ConvGeom, dy, w_dgrad, addend=None, out_f32=False, out=None):
     """dx = conv^T(dy) (+ addend: the skip-connection gradient, fused into the epilogue).  out_f32 (mixed mode, needs
     g.dgrad_mixed): bf16 operands, dx in float32; the addend may then be bf16 or float32."""
     assert tuple(dy.shape) == g.y_shape and not g.is_deconv
@@ -217,7 +225,7 @@ def conv_dgrad(g: ConvGeom, dy, w_dgrad, addend=None, out_f32=False):
         if pr: pr.stop()
         return dx
     assert addend is None or (tuple(addend.shape) == g.x_shape and addend.dtype == dy.dtype)
-    dx = torch.empty(g.x_shape, dtype=dy.dtype, device=dy.device)
+    dx = _out(out, g.x_shape, dy.dtype, dy.device)
     if pr: pr.start()
     A.check(A.lib().sgg_conv2d_bwd_data(C.byref(g.desc), _p(dy), _p(w_dgrad), _p(addend), _p(dx), _p(ws), g.ws_dgrad, _s()), "conv2d_bwd_data")
     if pr: pr.stop()
@@ -265,17 +273,17 @@ def conv_wgrad_pair(g: ConvGeom, x0, dy0, x1, dy1, dw, accumulate=False):
     if pr: pr.stop()
 
 
-def deconv_fwd(g: ConvGeom, x, w_dgrad, bias, act=A.ACT_NONE, leak=0.0):
+def deconv_fwd(g: ConvGeom, x, w_dgrad, bias, act=A.ACT_NONE, leak=0.0, out=None):
     assert tuple(x.shape) == g.x_shape and g.is_deconv
-    y = torch.empty(g.y_shape, dtype=x.dtype, device=x.device)
+    y = _out(out, g.y_shape, x.dtype, x.device)
     ws = workspace(g.ws_fwd, x.device) if g.ws_fwd else None
     A.check(A.lib().sgg_deconv2d_fwd(C.byref(g.desc), _p(x), _p(w_dgrad), _p(bias), _p(y), act, leak, _p(ws), g.ws_fwd, _s()), "deconv2d_fwd")
     return y
 
 
-def deconv_dgrad(g: ConvGeom, dy, w_fwd):
+def deconv_dgrad(g: ConvGeom, dy, w_fwd, out=None):
     assert tuple(dy.shape) == g.y_shape and g.is_deconv
-    dx = torch.empty(g.x_shape, dtype=dy.dtype, device=dy.device)
+    dx = _out(out, g.x_shape, dy.dtype, dy.device)
     ws = workspace(g.ws_dgrad, dy.device) if g.ws_dgrad else None
     A.check(A.lib().sgg_deconv2d_bwd_data(C.byref(g.desc), _p(dy), _p(w_fwd), _p(dx), _p(ws), g.ws_dgrad, _s()), "deconv2d_bwd_data")
     return dx
@@ -349,6 +357,40 @@ def instnorm_bwd_partial(dy, x, partial, gamma, beta, stats, dgamma, dbeta, accu
     A.check(A.lib().sgg_instnorm_bwd_partial(_p(dy), _p(x), _p(gamma), _p(beta), _p(stats), _p(dx), _p(dgamma), _p(dbeta), _p(partial),
                                              partial.shape[1], N, H * W, Cp, dgamma.numel(), int(accumulate), act, leak, dt(x),
                                              _p(ws), ws.numel(), _s()), "instnorm_bwd_partial")
+    return dx
+
+
+# ---- two networks of the same shape on one stacked batch (images 0..nsplit-1: first network; the rest: second)
+def instnorm_fwd_pair(x, gamma, beta, gamma2, beta2, nsplit, residual=None, eps=1e-3, act=A.ACT_NONE, leak=0.0):
+    N, H, W, Cp = x.shape
+    assert gamma.numel() == Cp and gamma2.numel() == Cp and 0 < nsplit < N
+    y = torch.empty_like(x)
+    stats = torch.empty((N, Cp, 2), dtype=torch.float32, device=x.device)
+    ws = workspace(int(A.lib().sgg_instnorm_workspace(N, H * W, Cp)), x.device)
+    A.check(A.lib().sgg_instnorm_fwd_pair(_p(x), _p(gamma), _p(beta), _p(gamma2), _p(beta2), nsplit, _p(residual), _p(y), _p(stats), N, H * W, Cp,
+                                          eps, act, leak, dt(x), _p(ws), ws.numel(), _s()), "instnorm_fwd_pair")
+    return y, stats
+
+
+def instnorm_fwd_partial_pair(x, partial, gamma, beta, gamma2, beta2, nsplit, residual=None, eps=1e-3, act=A.ACT_NONE, leak=0.0):
+    N, H, W, Cp = x.shape
+    assert gamma.numel() == Cp and gamma2.numel() == Cp and partial.shape[0] == N and partial.shape[2] == Cp and 0 < nsplit < N
+    y = torch.empty_like(x)
+    stats = torch.empty((N, Cp, 2), dtype=torch.float32, device=x.device)
+    A.check(A.lib().sgg_instnorm_fwd_partial_pair(_p(x), _p(gamma), _p(beta), _p(gamma2), _p(beta2), nsplit, _p(residual), _p(y), _p(stats),
+                                                  _p(partial), partial.shape[1], N, H * W, Cp, eps, act, leak, dt(x), _s()), "instnorm_fwd_partial_pair")
+    return y, stats
+
+
+def instnorm_bwd_pair(dy, x, gamma, beta, gamma2, beta2, nsplit, stats, dgamma, dbeta, dgamma2, dbeta2, accumulate=False,
+                      act=A.ACT_NONE, leak=0.0):
+    N, H, W, Cp = x.shape
+    assert dy.dtype == x.dtype and dgamma.numel() == dgamma2.numel() and 0 < nsplit < N
+    dx = torch.empty_like(x)
+    ws = workspace(int(A.lib().sgg_instnorm_workspace(N, H * W, Cp)), x.device)
+    A.check(A.lib().sgg_instnorm_bwd_pair(_p(dy), _p(x), _p(gamma), _p(beta), _p(gamma2), _p(beta2), nsplit, _p(stats), _p(dx), _p(dgamma), _p(dbeta),
+                                          _p(dgamma2), _p(dbeta2), N, H * W, Cp, dgamma.numel(), int(accumulate), act, leak, dt(x),
+                                          _p(ws), ws.numel(), _s()), "instnorm_bwd_pair")
     return dx
 
 

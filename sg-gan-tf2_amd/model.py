@@ -16,7 +16,7 @@ import torch
 from . import _abi as A
 from . import kernels as K
 from .graph import StepProgram
-from .module import Adam, Discriminator, Generator
+from .module import Adam, Discriminator, DiscriminatorPair, Generator, GeneratorPair
 from .utils import ImagePool
 
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32, "fp32": torch.float32,
@@ -29,7 +29,7 @@ def default_args(**over):
     a = dict(batch_size=1, image_height=128, image_width=128, input_nc=3, output_nc=3, ngf=64, ndf=64,
              segment_class=34, beta1=0.5, lr=0.0002, L1_lambda=10.0, Lg_lambda=5.0, use_resnet=True, use_pix2pix=False,
              use_lsgan=True, ratio_gan2seg=10, max_size=50, phase="train", dataset_dir="city",
-             dtype="bf16", device="cuda", n_blocks=9, seed=19, graph=False, mixed=False)
+             dtype="bf16", device="cuda", n_blocks=9, seed=19, graph=False, mixed=False, paired=True)
     a.update(over)
     return SimpleNamespace(**a)
 
@@ -93,6 +93,9 @@ class sggan(object):
         if self.cycle:
             self.g_optim_BA = Adam(self.generator_BA, lr, self.beta1)
             self.d_optim_B = Adam(self.discriminator_B, lr, self.beta1)
+        # cycle step: run the two generators (and the two discriminators) in lockstep on stacked batches (module._PairUnit);
+        # bit-identical to the one-network-at-a-time sequencing, which stays for the image pool and for mixed mode
+        self.paired = bool(g("paired", True))
         # mixed precision: bf16 storage, but the activation-gradient chain through the generators' residual blocks in f32
         self.mixed = bool(g("mixed", False)) and self.dtype == torch.bfloat16
         for net in self.networks():
@@ -267,6 +270,8 @@ class sggan(object):
         generator_loss / discriminator_loss (model.py:114-133) with criterionGAN = mae_criterion (--use_lsgan) or
         sce_criterion, abs_criterion cycle terms x --L1_lambda, gradloss_criterion x --Lg_lambda weighted by the
         segmentation-edge indicator (model.py:108-119).  Fakes in domain B are judged on A's mask and vice versa."""
+        if self.paired and not self.use_pool and not self.mixed:
+            return self._train_step_cycle_paired()
         Gab, Gba, Da, Db = self.generator, self.generator_BA, self.discriminator, self.discriminator_B
         prep_mask = lambda m: (m if isinstance(m, torch.Tensor) else torch.as_tensor(np.asarray(m, dtype=np.float32))).to(
             device=self.device, dtype=torch.float32).contiguous()
@@ -357,6 +362,73 @@ class sggan(object):
             opt.apply_gradients(grad_scale=scale)
         self.fake_A, self.fake_B = _LazyUnpad(fake_A, self.input_c_dim), _LazyUnpad(fake_B, C)
         self.cyc_A, self.cyc_B = _LazyUnpad(cyc_A, self.input_c_dim), _LazyUnpad(cyc_B, C)
+        return self.gen_loss, self.disc_loss
+
+    def _train_step_cycle_paired(self):
+        """The cycle step with the symmetric halves of the objective in lockstep: every activation tensor stacks the two
+        translation directions on the batch dimension -- [real_A; real_B] -> [fake_B; fake_A] -> [cyc_A; cyc_B] through
+        (G_A->B, G_B->A) then (G_B->A, G_A->B); the fakes through (D_B, D_A), the reals through (D_A, D_B).  Convolutions still
+        run per network; instance norms, activations and gradient joins run once per pair over twice the bytes.  Same kernels
+        per image, same accumulation order per network as _train_step_cycle: results are bit-identical to it."""
+        Gab, Gba, Da, Db = self.generator, self.generator_BA, self.discriminator, self.discriminator_B
+        if getattr(self, "_pairs", None) is None:
+            self._pairs = (GeneratorPair(Gab, Gba), GeneratorPair(Gba, Gab), DiscriminatorPair(Db, Da), DiscriminatorPair(Da, Db))
+        Gp1, Gp2, Dpf, Dpr = self._pairs
+        rA, rB = self._prep(self.real_A), self._prep(self.real_B)
+        sA, sB = self._prep(self.seg_A), self._prep(self.seg_B)
+        mA, mB = self._convert_input("mask_A", self.mask_A), self._convert_input("mask_B", self.mask_B)
+        for net in (Gab, Gba, Da, Db):
+            net.P.zero_grad()
+        C = self.output_c_dim
+        n = rA.shape[0]
+        lo, hi = slice(0, n), slice(n, 2 * n)
+        x1 = torch.cat([rA, rB])
+        m_ab = torch.cat([mA, mB])
+        f1, t1 = Gp1.forward(x1)                              # [fake_B; fake_A]
+        c2, t2 = Gp2.forward(f1)                              # [cyc_A; cyc_B]
+        Df, tDf = Dpf.forward(f1, m_ab)                       # [D_B(fake_B | mask_A); D_A(fake_A | mask_B)]
+        wA, wB = K.seg_edge_weight(sA, C), K.seg_edge_weight(sB, C)
+
+        crit = K.mse_const if self.use_lsgan else K.bce_logits
+        gl, dl = self._loss[0:1], self._loss[1:2]
+        e = torch.empty_like
+        g_g = e(Df)                                           # d g_loss / d logits, stacked like Df
+        crit(Df[hi], 1.0, gl, g_g[hi])                        # D_A(fake_A)   (the loss terms in _train_step_cycle's order)
+        crit(Df[lo], 1.0, gl, g_g[lo], accumulate_loss=True)  # D_B(fake_B)
+        d_cyc = e(c2)
+        K.l1_loss(rA, c2[lo], C, gl, d_cyc[lo], weight=self.L1_lambda, accumulate=True)
+        K.l1_loss(rB, c2[hi], C, gl, d_cyc[hi], weight=self.L1_lambda, accumulate=True)
+        d_f = e(f1)                                           # gradient-sensitive terms write, the rest accumulate
+        K.gradloss(f1[hi], rB, wB, C, gl, d_f[hi], lam=self.Lg_lambda, accumulate_loss=True)
+        K.gradloss(f1[lo], rA, wA, C, gl, d_f[lo], lam=self.Lg_lambda, accumulate_loss=True)
+
+        # discriminator gradients (fakes are constants here): reals through (D_A, D_B), fakes through (D_B, D_A)
+        Dr, tDr = Dpr.forward(x1, m_ab)                       # [D_A(real_A | mask_A); D_B(real_B | mask_B)]
+        g_r, g_fk = e(Dr), e(Df)
+        crit(Dr[lo], 1.0, dl, g_r[lo], weight=0.5, accumulate_loss=False)
+        crit(Df[hi], 0.0, dl, g_fk[hi], weight=0.5, accumulate_loss=True)
+        crit(Dr[hi], 1.0, dl, g_r[hi], weight=0.5, accumulate_loss=True)
+        crit(Df[lo], 0.0, dl, g_fk[lo], weight=0.5, accumulate_loss=True)
+        Dpr.backward(tDr, g_r)
+        Dpf.backward(tDf, g_fk)
+        hDa, hDb = self._allreduce(Da), self._allreduce(Db)
+        # generator gradients: cycle terms first (they reach the other generator through the fakes).  Each generator is applied
+        # twice, so the weight gradients of its 3x3 layers are paired: deferred in the first pass, launched with the second
+        Gab.pair_wgrads = Gba.pair_wgrads = self.pair_wgrads
+        d_f = K.add(d_f, Gp2.backward(t2, d_cyc, want_dx=True))
+        d_f = K.add(d_f, Dpf.backward(tDf, g_g, want_dx=True, param_grads=False))
+        Gp1.backward(t1, d_f)
+        Gba.flush_wgrads(); Gab.flush_wgrads()
+        Gab.pair_wgrads = Gba.pair_wgrads = False
+        hGba, hGab = self._allreduce(Gba), self._allreduce(Gab)
+
+        scale = 1.0 / self._world
+        for opt, h in ((self.d_optim, hDa), (self.d_optim_B, hDb), (self.g_optim_BA, hGba), (self.g_optim, hGab)):
+            if h is not None:
+                h.wait()
+            opt.apply_gradients(grad_scale=scale)
+        self.fake_A, self.fake_B = _LazyUnpad(f1[hi], self.input_c_dim), _LazyUnpad(f1[lo], C)
+        self.cyc_A, self.cyc_B = _LazyUnpad(c2[lo], self.input_c_dim), _LazyUnpad(c2[hi], C)
         return self.gen_loss, self.disc_loss
 
     # ------------------------------------------------------------------ convenience

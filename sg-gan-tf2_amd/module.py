@@ -271,6 +271,24 @@ class _ConvUnit:
         y, stats = K.instnorm_fwd(xc, P.p(n + "_g"), P.p(n + "_beta"), residual, self.net.eps, self.act, self.leak)
         return y, (g, x, xc, stats)
 
+    def weight_grad(self, g, x, dxc, gbuf=None):
+        """dW += wgrad(x, dxc).  When the net is applied twice this step (pair_wgrads) the first application's operands are
+        kept and both weight gradients run as ONE launch when the second arrives (one set of split slabs, one reduce)."""
+        P, n = self.net.P, self.name
+        if self.kind == "conv" and g.wgrad_pair and self.net.pair_wgrads and gbuf is None:
+            if self._pending is None:
+                self._pending = (g, x, dxc)
+            else:
+                g0, x0, d0 = self._pending
+                self._pending = None
+                if g0.x_shape == g.x_shape:
+                    K.conv_wgrad_pair(g, x0, d0, x, dxc, P.g(n + "_w"), accumulate=True)
+                else:
+                    K.conv_wgrad(g0, x0, d0, P.g(n + "_w"), accumulate=True)
+                    K.conv_wgrad(g, x, dxc, P.g(n + "_w"), accumulate=True)
+        else:
+            (K.conv_wgrad if self.kind == "conv" else K.deconv_wgrad)(g, x, dxc, P.g(n + "_w", buf=gbuf), accumulate=True)
+
     def backward(self, rec, dy, want_dx=True, param_grads=True, gbuf=None, addend=None, dy_partial=None, next_norm=None):
         """dy_partial: the norm-backward partial sums of THIS unit's norm, already computed by the data gradient that
         produced dy.  next_norm = (unit, rec) of the layer that will consume the returned dx: if its norm's first pass can
@@ -295,21 +313,7 @@ class _ConvUnit:
             if param_grads:
                 K.bias_grad(dxc, P.g(n + "_b", buf=gbuf), accumulate=True)
         if param_grads:
-            if self.kind == "conv" and g.wgrad_pair and self.net.pair_wgrads and gbuf is None:
-                # the net is applied twice this step: keep the first application's operands and run both weight
-                # gradients as ONE launch when the second arrives (one set of split slabs, one reduce)
-                if self._pending is None:
-                    self._pending = (g, x, dxc)
-                else:
-                    g0, x0, d0 = self._pending
-                    self._pending = None
-                    if g0.x_shape == g.x_shape:
-                        K.conv_wgrad_pair(g, x0, d0, x, dxc, P.g(n + "_w"), accumulate=True)
-                    else:
-                        K.conv_wgrad(g0, x0, d0, P.g(n + "_w"), accumulate=True)
-                        K.conv_wgrad(g, x, dxc, P.g(n + "_w"), accumulate=True)
-            else:
-                (K.conv_wgrad if self.kind == "conv" else K.deconv_wgrad)(g, x, dxc, P.g(n + "_w", buf=gbuf), accumulate=True)
+            self.weight_grad(g, x, dxc, gbuf)
         if not want_dx:
             return None
         if self.kind == "conv":
@@ -528,6 +532,152 @@ class Discriminator(_Net):
     def _run_backward(self, tape, dlogits, gbuf, want_dx):
         dx = self.backward(tape, dlogits, want_dx, True, gbuf)
         return None if dx is None else K.unpad_channels(dx, self.in_c)
+
+
+# ----------------------------------------------------------------------------- two networks in lockstep
+class _PairUnit:
+    """The same call site of TWO networks of one shape (G_A->B / G_B->A, D_A / D_B), applied to a batch that stacks their
+    activations: images [:n] belong to ``ua``'s network, [n:] to ``ub``'s.  The convolutions run per half with each network's
+    weights (into slices of one stacked output); the instance norm -- per image -- runs ONCE over the stacked tensor with the
+    affine parameters picked by image index (sgg_instnorm_*_pair): twice the bytes per launch (a 67 MB pass reaches 5-5.5 TB/s,
+    a 33 MB one 4.1-4.5), half the launches, and per image exactly the arithmetic of two separate calls."""
+
+    def __init__(self, ua, ub):
+        assert (ua.kind, ua.stride, ua.padding, ua.reflect, ua.norm, ua.act, ua.leak, ua.R, ua.cin, ua.cout) == \
+               (ub.kind, ub.stride, ub.padding, ub.reflect, ub.norm, ub.act, ub.leak, ub.R, ub.cin, ub.cout)
+        self.ua, self.ub = ua, ub
+
+    def forward(self, x, residual=None):
+        ua, ub = self.ua, self.ub
+        n = x.shape[0] // 2
+        halves = ((ua, slice(0, n)), (ub, slice(n, 2 * n)))
+        g = ua.geom(x[:n])
+        na, nb = ua.name, ub.name
+        PA, PB = ua.net.P, ub.net.P
+        xc = torch.empty((2 * n,) + tuple(g.y_shape[1:]), dtype=x.dtype, device=x.device)
+        fused_act = A.ACT_NONE if ua.norm else ua.act
+        if ua.kind == "conv" and ua.norm and g.stats_chunks and FUSE_CONV_IN_STATS:
+            part = torch.empty((2 * n, g.stats_chunks, g.y_shape[3], 2), dtype=torch.float32, device=x.device)
+            for u, sl in halves:
+                wf, _ = u.packed(x.dtype)
+                K.conv_fwd_stats(g, x[sl], wf, u.net.P.p(u.name + "_b"), out=xc[sl], out_partial=part[sl])
+            y, stats = K.instnorm_fwd_partial_pair(xc, part, PA.p(na + "_g"), PA.p(na + "_beta"), PB.p(nb + "_g"), PB.p(nb + "_beta"), n,
+                                                   residual, ua.net.eps, ua.act, ua.leak)
+            return y, (g, x, xc, stats)
+        for u, sl in halves:
+            wf, wd = u.packed(x.dtype)
+            if u.kind == "conv":
+                K.conv_fwd(g, x[sl], wf, u.net.P.p(u.name + "_b"), fused_act, u.leak, out=xc[sl])
+            else:
+                K.deconv_fwd(g, x[sl], wd, u.net.P.p(u.name + "_b"), fused_act, u.leak, out=xc[sl])
+        if not ua.norm:
+            return xc, (g, x, xc, None)
+        y, stats = K.instnorm_fwd_pair(xc, PA.p(na + "_g"), PA.p(na + "_beta"), PB.p(nb + "_g"), PB.p(nb + "_beta"), n,
+                                       residual, ua.net.eps, ua.act, ua.leak)
+        return y, (g, x, xc, stats)
+
+    def backward(self, rec, dy, want_dx=True, param_grads=True, addend=None):
+        ua, ub = self.ua, self.ub
+        g, x, xc, stats = rec
+        n = x.shape[0] // 2
+        halves = ((ua, slice(0, n)), (ub, slice(n, 2 * n)))
+        na, nb = ua.name, ub.name
+        PA, PB = ua.net.P, ub.net.P
+        if ua.norm:
+            if param_grads:
+                grads = (PA.g(na + "_g"), PA.g(na + "_beta"), PB.g(nb + "_g"), PB.g(nb + "_beta"))
+            else:                                         # gradients w.r.t. gamma / beta not wanted: send them to scratch
+                sa, sb = ua.net.scratch_vec(K.cpad(ua.cout)), ub.net.scratch_vec(K.cpad(ub.cout))
+                grads = (sa, sa, sb, sb)
+            dxc = K.instnorm_bwd_pair(dy, xc, PA.p(na + "_g"), PA.p(na + "_beta"), PB.p(nb + "_g"), PB.p(nb + "_beta"), n, stats,
+                                      *grads, param_grads, ua.act, ua.leak)
+            # (the conv bias in front of an instance norm has an identically zero gradient: left at 0)
+        else:
+            dxc = K.act_bwd(dy, xc, ua.act, ua.leak) if ua.act != A.ACT_NONE else dy
+            if param_grads:
+                for u, sl in halves:
+                    K.bias_grad(dxc[sl], u.net.P.g(u.name + "_b"), accumulate=True)
+        if param_grads:
+            for u, sl in halves:
+                u.weight_grad(g, x[sl], dxc[sl])
+        if not want_dx:
+            return None
+        dx = torch.empty((2 * n,) + tuple(g.x_shape[1:]), dtype=dxc.dtype, device=dxc.device)
+        for u, sl in halves:
+            wf, wd = u.packed(x.dtype)
+            if u.kind == "conv":
+                K.conv_dgrad(g, dxc[sl], wd, None if addend is None else addend[sl], out=dx[sl])
+            else:
+                K.deconv_dgrad(g, dxc[sl], wf, out=dx[sl])
+        if ua.kind != "conv" and addend is not None:
+            dx = K.add(dx, addend)
+        return dx
+
+
+class GeneratorPair:
+    """generator_resnet (module.py:219-269) of two generators in lockstep: forward([x_a; x_b]) = [G_a(x_a); G_b(x_b)]."""
+
+    def __init__(self, ga, gb):
+        assert ga.n_blocks == gb.n_blocks
+        self.a, self.b = ga, gb
+        P = _PairUnit
+        self.head = [P(ga.c1, gb.c1), P(ga.c2, gb.c2), P(ga.c3, gb.c3)]
+        self.blocks = [(P(xa, xb), P(ya, yb)) for (xa, ya), (xb, yb) in zip(ga.blocks, gb.blocks)]
+        self.tail = [P(ga.d1, gb.d1), P(ga.d2, gb.d2), P(ga.out, gb.out)]
+
+    def forward(self, x):
+        tape, h = [], x
+        for u in self.head:
+            h, r = u.forward(h)
+            tape.append(r)
+        for ua, ub in self.blocks:
+            y, ra = ua.forward(h)
+            h, rb = ub.forward(y, residual=h)             # IN(conv(y)) + x   (module.py:216-217)
+            tape.append((ra, rb))
+        for u in self.tail:
+            h, r = u.forward(h)
+            tape.append(r)
+        return h, tape
+
+    def backward(self, tape, dy, want_dx=False, param_grads=True):
+        nb = len(self.blocks)
+        d = dy
+        for u, r in zip(reversed(self.tail), (tape[5 + nb], tape[4 + nb], tape[3 + nb])):
+            d = u.backward(r, d, True, param_grads)
+        for (ua, ub), (ra, rb) in zip(reversed(self.blocks), reversed(tape[3:3 + nb])):
+            t = ub.backward(rb, d, True, param_grads)
+            d = ua.backward(ra, t, True, param_grads, addend=d)      # + skip gradient (fused into the data-gradient epilogue)
+        d = self.head[2].backward(tape[2], d, True, param_grads)
+        d = self.head[1].backward(tape[1], d, True, param_grads)
+        return self.head[0].backward(tape[0], d, want_dx, param_grads)
+
+
+class DiscriminatorPair:
+    """discriminator (module.py:272-318) of two discriminators in lockstep on stacked images and masks."""
+
+    def __init__(self, da, db):
+        self.a, self.b = da, db
+        self.units = [_PairUnit(ua, ub) for ua, ub in zip(da.units, db.units)]
+        self.h4 = _PairUnit(da.h4, db.h4)
+
+    def forward(self, x, mask):
+        tape, h = [], x
+        for u in self.units:
+            h, r = u.forward(h)
+            tape.append(r)
+        h4, r = self.h4.forward(h)
+        tape.append(r)
+        out = K.mask_reduce_fwd(h4, mask, self.a.segment_class)                    # module.py:312-314
+        tape.append((mask, tuple(h4.shape)))
+        return out, tape
+
+    def backward(self, tape, dlogits, want_dx=False, param_grads=True):
+        mask, h4_shape = tape[-1]
+        d = K.mask_reduce_bwd(dlogits.contiguous(), mask, h4_shape, self.a.dtype, self.a.segment_class)
+        d = self.h4.backward(tape[-2], d, True, param_grads)
+        for i in range(len(self.units) - 1, -1, -1):
+            d = self.units[i].backward(tape[i], d, want_dx or i > 0, param_grads)
+        return d
 
 
 # ----------------------------------------------------------------------------- autograd facade

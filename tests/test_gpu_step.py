@@ -335,7 +335,7 @@ def test_fused_paths_match_unfused_at_bench_width(sg):
         for k in calls:
             calls[k] = 0
         try:
-            m = sg.sggan(sg.default_args(dtype="bf16", cycle=True, n_blocks=2, pair_wgrads=pair))
+            m = sg.sggan(sg.default_args(dtype="bf16", cycle=True, n_blocks=2, pair_wgrads=pair, paired=False))   # the one-network engine's paths
             a = _rand_inputs(1, 256, 512, m.discriminator, 5)
             b = _rand_inputs(1, 256, 512, m.discriminator, 6)
             m.real_A, m.seg_A, m.mask_A = a
@@ -460,3 +460,23 @@ def test_other_baseline_configs_run(sg, cfg):
     assert np.isfinite(gl) and np.isfinite(dl), (gl, dl)
     f = m.fake_A.numpy()
     assert f.shape == (N, H, W, 3) and np.isfinite(f).all() and np.abs(f).max() <= 1.0
+
+
+@pytest.mark.parametrize("cfg", [("f32", 16, 2, 2, 256, 256), ("bf16", 16, 2, 2, 256, 256), ("bf16", 64, 2, 1, 256, 512)],
+                         ids=["f32_small", "bf16_small", "bf16_full_width_halo_paths"])
+def test_paired_cycle_step_is_bit_identical_to_one_network_at_a_time(sg, cfg):
+    """The lockstep sequencing of the cycle step (module._PairUnit: both generators / both discriminators on stacked batches,
+    one instance-norm launch per pair) against the one-network-at-a-time sequencing: same kernels per image and the same
+    accumulation order per network, so parameters, Adam slots, gradients, losses and images after two steps are bitwise equal."""
+    dtype, width, blocks, N, H, W = cfg
+    out = []
+    for paired in (False, True):
+        m = sg.sggan(sg.default_args(ngf=width, ndf=width, n_blocks=blocks, dtype=dtype, cycle=True, paired=paired))
+        m.real_A, m.seg_A, m.mask_A = _rand_inputs(N, H, W, m.discriminator, 61)
+        m.real_B, m.seg_B, m.mask_B = _rand_inputs(N, H, W, m.discriminator, 62)
+        for _ in range(2):
+            m.train_step()
+        out.append([t.clone() for n in m.networks() for t in (n.P.flat, n.P.m, n.P.v, n.P.grad)] +
+                   [m._loss.clone(), m.fake_A.tensor(), m.fake_B.tensor(), m.cyc_A.tensor(), m.cyc_B.tensor()])
+    for i, (a, b) in enumerate(zip(*out)):
+        assert torch.equal(a, b), i

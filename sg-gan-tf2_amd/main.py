@@ -44,6 +44,7 @@ def build_parser():
     a("--cycle", dest="cycle", action="store_true", help="2G+2D cycle-mode step (north_star unit)")
     a("--dtype", dest="dtype", default="bf16")
     a("--steps_per_epoch", dest="steps_per_epoch", type=int, default=4)
+    a("--log_dir", dest="log_dir", default="./logs", help="scalar summaries (the reference writes tfevents under logs/<timestamp>/train)")
     return p
 
 
@@ -72,12 +73,32 @@ def synthetic_batches(model, args):
     return gen
 
 
+def synthetic_test_samples(args, count=2):
+    """(name, sample_image, seg_image) triples in the reference loader's ranges (utils.load_test_data: floats in [0,1])."""
+    import torch
+
+    def gen(epoch=0):
+        g = torch.Generator().manual_seed(1000 + epoch)
+        H, W = args.image_height, args.image_width
+        for i in range(count):
+            yield "synthetic_%03d.png" % i, torch.rand((H, W, 3), generator=g).numpy(), torch.rand((H, W, 3), generator=g).numpy()
+    return gen
+
+
 def main(argv=None):
+    """main.py:45-60: ``--phase train`` runs the epoch loop (with the epoch-end test pass and scalar summaries of
+    model.py:263-268), ``--phase test`` the test pass of model.py:535-567 -- here on synthetic data (dataset files and their
+    decoding are host-side I/O outside the hot path)."""
     args = build_parser().parse_args(argv)
     args.use_resnet = True            # the only generator on the hot path (SURVEY.md 2.1)
     from .model import sggan
+    from .utils import SummarySink
     model = sggan(args)
-    return model.train(args, synthetic_batches(model, args))
+    if args.phase == "test":          # main.py:58-60
+        return model.test(args, synthetic_test_samples(args)())
+    import os
+    sink = SummarySink(os.path.join(getattr(args, "log_dir", "./logs"), "train", "scalars.jsonl"))
+    return model.train(args, synthetic_batches(model, args), test_samples=synthetic_test_samples(args), sink=sink)
 
 
 if __name__ == "__main__":

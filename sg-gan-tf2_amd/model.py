@@ -483,10 +483,60 @@ class sggan(object):
         self.load_state_dict(sd)
         return True
 
-    def train(self, args, batches, log=print):
+    def test_during_train(self, epoch, args, samples, sink=None):
+        """model.py:307-448 (the live part: the CRF variants are commented out there and pydensecrf is out of scope): every
+        test sample -- ``samples`` yields (name, sample_image (H,W,3) in [0,1], seg_image (H,W,3) in [0,1]); reading and
+        resizing the files (utils.load_test_data) stays on the caller's side -- is rescaled like the reference does
+        (tf.image.convert_image_dtype -> uint8 -> float32), translated by the generator, optionally saved under
+        ``args.test_dir``, and labelled against its segmentation image (metric.scores_seg_fake); the FCN scores of all labels
+        go to ``sink`` under the reference's scalar names.  Returns (the stacked fake images as model.py:440-448 does, scores)."""
+        from . import metric as M
+        from .utils import convert_image_dtype_uint8, get_img, save_images
+        import os
+        gts, preds, outputs = [], [], []
+        test_dir = getattr(args, "test_dir", None)
+        for name, sample_image, seg_image in samples:
+            rescaled = convert_image_dtype_uint8(np.asarray(sample_image)[None])                 # :352-353
+            fake_A = self.generator(torch.as_tensor(rescaled).to(self.device))                   # :357
+            if test_dir:
+                os.makedirs(test_dir, exist_ok=True)
+                save_images(fake_A, [1, 1], os.path.join(test_dir, os.path.basename(name)))      # :362-365
+            fake_img = get_img(fake_A, [1, 1])                                                   # :369
+            outputs.append(fake_img)
+            lt, lp = M.scores_seg_fake(np.asarray(seg_image, dtype=np.float32)[None], torch.as_tensor(fake_img.astype(np.float32)))   # :373
+            preds += list(lp); gts += list(lt)
+        score = M.scores(gts, preds, n_class=args.segment_class)                                 # :378
+        if sink is not None:                                                                     # :389-393
+            sink.scalar("Overall Accuracy", score["Overall Acc"], epoch)
+            sink.scalar("Mean Accuracy", score["Mean Acc"], epoch)
+            sink.scalar("Frequency Weighted Accuracy", score["FreqW Acc"], epoch)
+            sink.scalar("Mean IoU", score["Mean IoU"], epoch)
+        return (np.concatenate(outputs, axis=0) if outputs else None), score
+
+    def test(self, args, samples, log=print):
+        """model.py:535-567 (--phase test): load the latest checkpoint, translate every test sample and save the input and the
+        translation under ``args.test_dir``.  ``samples`` yields (name, sample_image (H,W,3) in [0,1])."""
+        from .utils import convert_image_dtype_uint8, save_images
+        import os
+        log(" [*] Running Test ...")
+        log(" [*] Load SUCCESS" if self.load(args.checkpoint_dir) else " [!] Load failed...")
+        os.makedirs(args.test_dir, exist_ok=True)
+        out = []
+        for item in samples:
+            name, sample_image = item[0], np.asarray(item[1], dtype=np.float32)
+            log("Processing image: " + name)
+            rescaled = convert_image_dtype_uint8(sample_image[None])
+            fake_A = self.generator(torch.as_tensor(rescaled).to(self.device))
+            save_images(sample_image[None], [1, 1], os.path.join(args.test_dir, "real_" + os.path.basename(name)))
+            save_images(fake_A, [1, 1], os.path.join(args.test_dir, os.path.basename(name)))
+            out.append(fake_A)
+        return out
+
+    def train(self, args, batches, log=print, test_samples=None, sink=None):
         """The reference's epoch loop (model.py:202-275) around ``train_step`` for a caller-supplied batch source:
         ``batches(epoch)`` yields dicts with real_A / seg_A / mask_A (+ real_B / seg_B / mask_B in cycle mode) --
-        disk loading and augmentation (utils.py:167-233) stay on the caller's side.  Prints the reference's line
+        disk loading and augmentation (utils.py:167-233) stay on the caller's side; ``test_samples`` / ``sink`` add the epoch-end
+        test pass and the scalar summaries of model.py:263-268.  Prints the reference's line
         (model.py:260), keeps its running-mean loss metrics (model.py:23-24,193-194,270-271), honours
         --continue_train (model.py:210-215) and saves in ``finally`` like model.py:272-275."""
         import time
@@ -511,6 +561,14 @@ class sggan(object):
                     self.gen_loss_metric += (gl - self.gen_loss_metric) / self._metric_n
                     self.disc_loss_metric += (dl - self.disc_loss_metric) / self._metric_n
                     log("Epoch: [%2d] [%4d/%4d] time: %4.4f Gen_Loss: %f Disc_Loss: %f " % (epoch, idx, len(data), time.time() - start, gl, dl))
+                # epoch end (model.py:263-268): the test pass + image summary, then the two running-mean loss scalars
+                if test_samples is not None:
+                    fake, _ = self.test_during_train(epoch, args, test_samples(epoch) if callable(test_samples) else test_samples, sink)
+                    if sink is not None and fake is not None:
+                        sink.image("Segmentation Epoch {}".format(epoch), fake, epoch)
+                if sink is not None:
+                    sink.scalar("Generator Loss", self.gen_loss_metric, epoch)
+                    sink.scalar("Discriminator Loss", self.disc_loss_metric, epoch)
                 history.append({"epoch": epoch, "Generator Loss": self.gen_loss_metric, "Discriminator Loss": self.disc_loss_metric})
         finally:
             if getattr(args, "checkpoint_dir", None):

@@ -44,3 +44,64 @@ class ImagePool(object):
             self.images[idx][1], self.images[idx][3] = image[1].clone(), image[3].clone()
             return [tmp1, tmp2, tmp3, tmp4]
         return image                                           # :52-53
+
+
+# ----------------------------------------------------------------------------- image helpers of the test paths
+def inverse_transform(images):
+    """utils.py:300-312: tanh range [-1,1] -> uint8 [0,255] (C cast: truncation)."""
+    a = images.tensor() if hasattr(images, "tensor") else images
+    a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float32)
+    return np.array(((a + 1.) / 2) * 255).astype(np.uint8)
+
+
+def merge(images, size):
+    """utils.py:261-269: tile (B,h,w,3) images on a size[0] x size[1] grid."""
+    h, w = images.shape[1], images.shape[2]
+    img = np.zeros((h * size[0], w * size[1], 3))
+    for idx, image in enumerate(images):
+        i, j = idx % size[1], idx // size[1]
+        img[j * h:j * h + h, i * w:i * w + w, :] = image
+    return np.array(img).astype(np.uint8)
+
+
+def get_img(image, size):
+    """utils.py:243-247: (1, H*size0, W*size1, 3) uint8 array of the tiled, inverse-transformed images."""
+    img = merge(inverse_transform(image), size)
+    return img.reshape((1,) + img.shape)
+
+
+def save_images(images, size, image_path):
+    """utils.py:239-241 (imsave of the merged inverse transform); PNG/JPEG writing is host-side I/O (PIL)."""
+    from PIL import Image
+    Image.fromarray(merge(inverse_transform(images), size)).save(image_path)
+
+
+def convert_image_dtype_uint8(sample):
+    """tf.image.convert_image_dtype(float image in [0,1], uint8) as model.py:352,551 uses it: [3P] scale by dtype.max + 0.5 and
+    cast (truncate); returned as float32 like the reference's ``np.array(...).astype(np.float32)`` -- i.e. the test paths feed
+    the generator 0..255 values (the training loop feeds [0,1]; that is the reference's behaviour, reproduced, not endorsed)."""
+    a = np.asarray(sample, dtype=np.float32)
+    return (a * np.float32(255.5)).astype(np.uint8).astype(np.float32)
+
+
+class SummarySink:
+    """Scalar summaries of the epoch loop (model.py:263-268, 389-393: tf.summary.scalar under a train writer).  TensorFlow's
+    event-file writer is not part of this build; the sink keeps the reference's scalar NAMES and steps, in memory and (optionally)
+    as JSON lines -- one {"tag", "step", "value"} object per call -- which any tfevents writer can replay."""
+
+    def __init__(self, path=None):
+        self.path, self.records = path, []
+        if path:
+            import os
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+
+    def scalar(self, tag, value, step):
+        rec = {"tag": tag, "step": int(step), "value": float(value)}
+        self.records.append(rec)
+        if self.path:
+            import json
+            with open(self.path, "a") as f:
+                f.write(json.dumps(rec) + "\n")
+
+    def image(self, tag, array, step):
+        self.records.append({"tag": tag, "step": int(step), "image_shape": tuple(np.asarray(array).shape)})

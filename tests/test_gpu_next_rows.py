@@ -96,3 +96,47 @@ def test_cycle_step_with_image_pool(sg):
     assert o0[0] == o1[0] and o0[1] == o1[1]                  # pool not yet full: same losses
     assert m1.pool.num_img == 2 and all(np.isfinite(v) for pair in o1 for v in pair)
     assert o0 != o1                                           # after it fills, D sees older fakes at least once
+
+
+def test_epoch_end_test_pass_scores_and_summaries(sg, tmp_path):
+    """model.py:263-268 + 307-448: the epoch-end test pass.  Labels / FCN scores must equal the oracle's restatement evaluated
+    on the images the GPU path produced (bit exact: integer label maps, float64 score arithmetic); the summary sink carries the
+    reference's scalar names; --phase test (model.py:535-567) loads the checkpoint and writes real_/translated images."""
+    from sggan_amd.utils import SummarySink, convert_image_dtype_uint8, get_img
+    from sggan_amd.main import build_parser, synthetic_batches, synthetic_test_samples
+    args = build_parser().parse_args(["--img_height", "128", "--img_width", "128", "--ngf", "8", "--ndf", "8", "--epoch", "2",
+                                      "--batch_size", "2", "--steps_per_epoch", "2", "--dtype", "f32", "--segment_class", "34",
+                                      "--checkpoint_dir", str(tmp_path / "ckpt"), "--test_dir", str(tmp_path / "test")])
+    args.use_resnet, args.n_blocks = True, 2
+    m = sg.sggan(args)
+    sink = SummarySink(str(tmp_path / "logs" / "train" / "scalars.jsonl"))
+    samples = synthetic_test_samples(args, count=3)
+    hist = m.train(args, synthetic_batches(m, args), log=lambda *a: None, test_samples=samples, sink=sink)
+    assert len(hist) == 2
+    tags = [r["tag"] for r in sink.records]
+    per_epoch = ["Overall Accuracy", "Mean Accuracy", "Frequency Weighted Accuracy", "Mean IoU", "Segmentation Epoch 0",
+                 "Generator Loss", "Discriminator Loss"]
+    assert tags[:7] == per_epoch and tags[7:11] == per_epoch[:4] and len(tags) == 14
+    assert sink.records[5]["value"] == hist[0]["Generator Loss"] and sink.records[13]["step"] == 1
+    import json
+    lines = [json.loads(l) for l in open(sink.path)]
+    assert [l["tag"] for l in lines] == [t for t in tags if not t.startswith("Segmentation")]
+    # the scores of a fresh pass against the oracle's restatement on the same generated images
+    fake, score = m.test_during_train(5, args, samples(0), None)
+    assert fake.shape == (3, 128, 128, 3) and fake.dtype == np.uint8
+    gts, preds = [], []
+    for i, (name, img, seg) in enumerate(samples(0)):
+        x = torch.as_tensor(convert_image_dtype_uint8(img[None])).cuda()
+        f = get_img(m.generator(x), [1, 1])
+        assert np.array_equal(f[0], fake[i])
+        lt, lp = O.scores_seg_fake(seg[None].astype(np.float32), f)
+        gts += list(lt); preds += list(lp)
+    exp = O.scores(gts, preds, 34)
+    for k in ("Overall Acc", "Mean Acc", "FreqW Acc", "Mean IoU"):
+        assert score[k] == exp[k] or (np.isnan(score[k]) and np.isnan(exp[k])), k
+    assert os.path.exists(tmp_path / "test" / "synthetic_000.png")
+    # --phase test
+    m2 = sg.sggan(args)
+    out = m2.test(args, synthetic_test_samples(args, count=2)(), log=lambda *a: None)
+    assert len(out) == 2 and os.path.exists(tmp_path / "test" / "real_synthetic_001.png")
+    assert torch.equal(m2.generator.P.flat, m.generator.P.flat)          # the checkpoint train() saved was loaded

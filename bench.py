@@ -129,11 +129,11 @@ class EventProfiler:
         if self.mode == "off":
             return None
         tag = None
-        if name == "conv2d_fwd" and hasattr(key, "desc"):
+        if name in ("conv2d_fwd", "conv2d_fwd_pair") and hasattr(key, "desc"):      # _pair: both generators' images in one launch
             d = key.desc
             if d.R == 3 and d.C == 256 and d.K == 256 and d.stride == 1 and d.pad_mode == 1:
                 tag = ("res_conv_fwd", d.N * d.Ho * d.Wo, d.K, d.R * d.S * d.C)
-        elif name == "conv2d_bwd_data" and hasattr(key, "desc"):
+        elif name in ("conv2d_bwd_data", "conv2d_bwd_data_pair") and hasattr(key, "desc"):
             d = key.desc
             if d.R == 3 and d.C == 256 and d.K == 256 and d.stride == 1 and d.pad_mode == 1:
                 tag = ("res_conv_dgrad", d.N * d.H * d.W, d.C, d.R * d.S * d.K)
@@ -370,7 +370,9 @@ def main():
                 kt[tag[0]] = {"avg_ms": ms, "avg_ms_raw_span": raw, "launches": n, "gbs": by / (ms * 1e-3) / 1e9, "mbytes_per_launch": by / 1e6}
         if "res_conv_fwd" in kt:
             k = kt["res_conv_fwd"]
-            line["roofline"] = {"bound": "mfma", "kernel": "conv3x3_halo_gemm_kernel<FWD, STATS> (bf16, 256x256 tile, 8 waves, input halo resident in LDS; 3x3 C=256 residual-block conv; the timed launch also computes the following instance norm's per-channel sums in its epilogue, ~4 us, not counted in the FLOPs)",
+            line["roofline"] = {"bound": "mfma", "kernel": "conv3x3_halo_gemm_kernel<FWD, STATS> (bf16, 256x256 tile, 8 waves, input halo resident in LDS; 3x3 C=256 residual-block conv; "
+                                          "in the cycle step one launch covers the stacked images of both generators -- gflop_per_launch says how many; the timed "
+                                          "launch also computes the following instance norm's per-channel sums in its epilogue, ~4 us, not counted in the FLOPs)",
                                 "achieved": k["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                 "frac": k["tflops"] / PEAK_BF16_TFLOPS, "traffic": measured_traffic("res_conv_fwd"),
                                 "avg_launch_ms": k["avg_ms"], "launches_timed": k["launches"], "gflop_per_launch": k["gflop_per_launch"],

@@ -115,6 +115,14 @@ int sgg_conv2d_bwd_data_stats(const sgg_conv_desc* d, const void* dy, const void
 int sgg_conv2d_bwd_data_mixed_supported(const sgg_conv_desc* d);
 int sgg_conv2d_bwd_data_mixed(const sgg_conv_desc* d, const void* dy, const void* w_dgrad, const void* addend, int addend_is_f32,
                               float* dx, void* ws, size_t ws_bytes, void* stream);
+/* The lockstep pair (see sgg_instnorm_*_pair): d describes the STACKED batch (N = both networks' images); images
+ * 0..nsplit-1 are convolved with (w, bias), the rest with (w2, bias2), in ONE launch -- where sgg_conv2d_pair_supported(d)
+ * returns 1 (the bf16 3x3 stride-1 kernels); elsewhere call the one-network entry points on the two halves. */
+int sgg_conv2d_pair_supported(const sgg_conv_desc* d);
+int sgg_conv2d_fwd_stats_pair(const sgg_conv_desc* d, const void* x, const void* w_fwd, const float* bias, const void* w_fwd2,
+                              const float* bias2, int nsplit, void* y, float* partial, void* ws, size_t ws_bytes, void* stream);
+int sgg_conv2d_bwd_data_pair(const sgg_conv_desc* d, const void* dy, const void* w_dgrad, const void* w_dgrad2, int nsplit,
+                             const void* addend, void* dx, void* ws, size_t ws_bytes, void* stream);
 /* bwd_weight: dw_hwio[R][S][C_real][K_real] f32, overwritten (accumulate=0) or added to (accumulate=1: a network
  * applied twice in one step, model.py:186-187).  ws: sgg_conv2d_bwd_weight_workspace() bytes. */
 size_t sgg_conv2d_bwd_weight_workspace(const sgg_conv_desc* d);

@@ -48,6 +48,9 @@ struct ConvArgs {
     int nact; float nleak;   // and the activation fused behind it
     float* partial;      // split-K (v2): f32 slabs [ksplit][pdst][DC]
     int ksplit;          // 1 = no split
+    const char* wmat2;   // halo 3x3 kernels, two networks on one stacked batch: images >= nsplit use wmat2 / bias2
+    const float* bias2;
+    int nsplit;          //   (INT_MAX: one network)
     int dst_f32;         // halo 3x3 data gradient, mixed mode: dst is f32 (the gradient chain between instance norms keeps f32)
     int addend_f32;      //   ... and so is the addend
     int ablate;          // lab build only (SGG_ABLATE; always 0 and compiled out otherwise): 1 no in-loop DMA, 2 no LDS reads/MFMAs, 3 = 1 + no barrier,
@@ -758,6 +761,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     const int th = mt % tilesH;
     const int img = mt / tilesH;
     const int h0 = th * 2, w0 = tw * H3_TW;
+    const char* const wmat_n = img >= a.nsplit ? a.wmat2 : a.wmat;       // (two networks stacked on the batch: per-image weights)
+    const float* const bias_n = img >= a.nsplit ? a.bias2 : a.bias;
     const bool dbg_clk = SGG_ABLATE_OF(a) == 9 && lid == 0 && tid == 0;
     const int abl = SGG_ABLATE_OF(a) >= 8 ? 0 : SGG_ABLATE_OF(a);    // 8, 9 = full kernel + clock stamps
     if (dbg_clk) { g_dbg_clk[0] = clock64(); g_dbg_clk[1] = wall_clock64(); }
@@ -820,7 +825,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     // ---- weight-tile DMA: 32 wave-instructions of 8 rows x 128 B per tile; instruction d covers rows 8d .. 8d+7, lane l row
     // 8d + l/8 at chunk position l%8 (swizzled by the row: key = (l/16 + 4(d&1)) & 7, i.e. the d-even key with bit 2 flipped)
     const int wl = lane >> 3;
-    const char* wbase = a.wmat + (size_t)(n0 + wl) * wrow * 2;
+    const char* wbase = wmat_n + (size_t)(n0 + wl) * wrow * 2;
     const int wsw = ((lane & 7) ^ ((lane >> 4) & 7)) << 4;
     const size_t wstride8 = (size_t)8 * wrow * 2;
     auto load_w = [&](int stg, int chunk, int tap, int vw, int nw) {
@@ -964,7 +969,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         for (int i = 0; i < NI; ++i) {
             const int dc = n0 + wn * WN + i * 16 + fq * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { bv[i][e] = (a.bias && dc < DC) ? a.bias[dc + e] : 0.f; s1[i][e] = s2[i][e] = 0.f; }
+            for (int e = 0; e < 4; ++e) { bv[i][e] = (bias_n && dc < DC) ? bias_n[dc + e] : 0.f; s1[i][e] = s2[i][e] = 0.f; }
         }
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
@@ -1049,7 +1054,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         float bv[4], s1[4], s2[4], mu[4], rs[4], gm[4], bt[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            bv[e] = a.bias ? a.bias[dc + e] : 0.f;
+            bv[e] = bias_n ? bias_n[dc + e] : 0.f;
             s1[e] = s2[e] = 0.f;
             if (STATS == 2) {
                 mu[e] = a.nstats[((size_t)img * DC + dc + e) * 2]; rs[e] = a.nstats[((size_t)img * DC + dc + e) * 2 + 1];
@@ -2855,7 +2860,7 @@ static bool desc_ok(const sgg_conv_desc* d) {
 
 static ConvArgs make_args(const sgg_conv_desc* d, const void* src, const void* w, const float* bias, void* dst, int act, float leak) {
     ConvArgs a;
-    a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst; a.addend = nullptr; a.fold = nullptr; a.stats = nullptr; a.nx = nullptr; a.nstats = nullptr; a.ngamma = nullptr; a.nbeta = nullptr; a.nact = 0; a.nleak = 0.f; a.partial = nullptr; a.ksplit = 1; a.pdst = 0; a.dst_f32 = 0; a.addend_f32 = 0;
+    a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst; a.addend = nullptr; a.fold = nullptr; a.stats = nullptr; a.nx = nullptr; a.nstats = nullptr; a.ngamma = nullptr; a.nbeta = nullptr; a.nact = 0; a.nleak = 0.f; a.partial = nullptr; a.ksplit = 1; a.pdst = 0; a.dst_f32 = 0; a.addend_f32 = 0; a.wmat2 = nullptr; a.bias2 = nullptr; a.nsplit = 0x7fffffff;
     a.ablate = sgg_config().ablate;
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S; a.stride = d->stride;
     a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.reflect = d->pad_mode == SGG_PAD_REFLECT;
@@ -3624,14 +3629,15 @@ size_t sgg_conv2d_bwd_data_workspace(const sgg_conv_desc* d) {
     return fold_bytes(d) + plan_gemm(d, MODE_DGRAD).ws_bytes;
 }
 
-struct NormBwdStats { const void* nx; const float* nstats; const float* ngamma; const float* nbeta; int nact; float nleak; float* partial; int mixed; };
+struct NormBwdStats { const void* nx; const float* nstats; const float* ngamma; const float* nbeta; int nact; float nleak; float* partial; int mixed; const void* w2; int nsplit; };
 
 static int conv2d_bwd_data_impl(const sgg_conv_desc* d, const void* dy, const void* w, const void* addend, void* dx, const NormBwdStats* nb,
                                 void* ws, size_t ws_bytes, void* stream) {
     if (!desc_ok(d) || !dy || !w || !dx) return SGG_EINVAL;
     ConvArgs a = make_args(d, dy, w, nullptr, dx, SGG_ACT_NONE, 0.f);
     a.addend = (const char*)addend;
-    if (nb && nb->mixed) { a.dst_f32 = nb->mixed & 1; a.addend_f32 = (nb->mixed >> 1) & 1; nb = nullptr; }
+    if (nb && nb->w2) { a.wmat2 = (const char*)nb->w2; a.nsplit = nb->nsplit; }
+    if (nb && (nb->mixed || nb->w2)) { a.dst_f32 = nb->mixed & 1; a.addend_f32 = (nb->mixed >> 1) & 1; nb = nullptr; }
     if (nb) {
         a.stats = nb->partial; a.nx = (const char*)nb->nx; a.nstats = nb->nstats; a.ngamma = nb->ngamma; a.nbeta = nb->nbeta;
         a.nact = nb->nact; a.nleak = nb->nleak;
@@ -3721,8 +3727,32 @@ int sgg_conv2d_bwd_data_stats(const sgg_conv_desc* d, const void* dy, const void
     if (!norm_x || !norm_stats || !norm_gamma || !norm_beta || !partial) return SGG_EINVAL;
     if (norm_act == SGG_ACT_TANH) return SGG_EUNSUPPORTED;
     if (sgg_conv2d_bwd_data_stats_chunks(d) == 0) return SGG_EUNSUPPORTED;
-    NormBwdStats nb{norm_x, norm_stats, norm_gamma, norm_beta, norm_act, norm_leak, partial, 0};
+    NormBwdStats nb{norm_x, norm_stats, norm_gamma, norm_beta, norm_act, norm_leak, partial, 0, nullptr, 0};
     return conv2d_bwd_data_impl(d, dy, w, addend, dx, &nb, ws, ws_bytes, stream);
+}
+
+// Two networks of one shape on a stacked batch (images >= nsplit use the second weight set): one launch of the LDS-resident
+// 3x3 kernels instead of two -- 512 blocks, so a CU's second block loads its halo while the first one's stores drain.
+int sgg_conv2d_pair_supported(const sgg_conv_desc* d) {
+    if (!desc_ok(d) || d->dtype != SGG_BF16 || d->N < 2) return 0;
+    ConvArgs a = make_args(d, nullptr, nullptr, nullptr, nullptr, SGG_ACT_NONE, 0.f);
+    return (plan_gemm(d, MODE_FWD).ksplit == 1 && plan_gemm(d, MODE_DGRAD).ksplit == 1 && halo3_ok(a, MODE_FWD, true) && halo3_ok(a, MODE_DGRAD, true)) ? 1 : 0;
+}
+int sgg_conv2d_fwd_stats_pair(const sgg_conv_desc* d, const void* x, const void* w, const float* bias, const void* w2, const float* bias2,
+                              int nsplit, void* y, float* partial, void* ws, size_t ws_bytes, void* stream) {
+    if (!sgg_conv2d_pair_supported(d)) return SGG_EUNSUPPORTED;
+    if (!x || !w || !w2 || !y || !partial || nsplit <= 0 || nsplit >= d->N) return SGG_EINVAL;
+    ConvArgs a = make_args(d, x, w, bias, y, SGG_ACT_NONE, 0.f);
+    a.stats = partial; a.wmat2 = (const char*)w2; a.bias2 = bias2; a.nsplit = nsplit;
+    return run_gemm<bf16, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream);
+}
+int sgg_conv2d_bwd_data_pair(const sgg_conv_desc* d, const void* dy, const void* w, const void* w2, int nsplit, const void* addend, void* dx,
+                             void* ws, size_t ws_bytes, void* stream) {
+    if (!sgg_conv2d_pair_supported(d)) return SGG_EUNSUPPORTED;
+    if (!w2 || nsplit <= 0 || nsplit >= d->N) return SGG_EINVAL;
+    NormBwdStats flags{};
+    flags.w2 = w2; flags.nsplit = nsplit;
+    return conv2d_bwd_data_impl(d, dy, w, addend, dx, &flags, ws, ws_bytes, stream);
 }
 
 size_t sgg_conv2d_bwd_weight_workspace(const sgg_conv_desc* d) {

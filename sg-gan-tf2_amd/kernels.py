@@ -87,7 +87,7 @@ def same_pads(n_in: int, k: int, s: int):
 
 class ConvGeom:
     """Geometry of one Conv2D / Conv2DTranspose call site, resolved to an sgg_conv_desc."""
-    __slots__ = ("desc", "x_shape", "y_shape", "ws_wgrad", "ws_dgrad", "ws_fwd", "dtype", "is_deconv", "stats_chunks", "wgrad_pair", "bwd_stats_chunks", "dgrad_mixed")
+    __slots__ = ("desc", "x_shape", "y_shape", "ws_wgrad", "ws_dgrad", "ws_fwd", "dtype", "is_deconv", "stats_chunks", "wgrad_pair", "bwd_stats_chunks", "dgrad_mixed", "pair_ok")
 
     def __init__(self, desc, x_shape, y_shape, dtype, is_deconv):
         self.desc, self.x_shape, self.y_shape, self.dtype, self.is_deconv = desc, x_shape, y_shape, dtype, is_deconv
@@ -101,6 +101,8 @@ class ConvGeom:
         self.bwd_stats_chunks = 0 if is_deconv else int(L.sgg_conv2d_bwd_data_stats_chunks(C.byref(desc)))
         # mixed mode: the data gradient can be written in f32 (bf16 operands) for the norm backward that consumes it
         self.dgrad_mixed = (not is_deconv) and bool(L.sgg_conv2d_bwd_data_mixed_supported(C.byref(desc)))
+        # a stacked batch of two networks can run forward (+stats) / data gradient as ONE launch with per-image weights
+        self.pair_ok = (not is_deconv) and bool(L.sgg_conv2d_pair_supported(C.byref(desc)))
         # workspaces of the two GEMM directions; a deconv runs the conv's data-gradient kernel forwards
         self.ws_fwd = int((L.sgg_deconv2d_fwd_workspace if is_deconv else L.sgg_conv2d_fwd_workspace)(C.byref(desc)))
         self.ws_dgrad = int((L.sgg_deconv2d_bwd_data_workspace if is_deconv else L.sgg_conv2d_bwd_data_workspace)(C.byref(desc)))
@@ -206,6 +208,33 @@ def conv_fwd_stats(g: ConvGeom, x, w_fwd, bias, out=None, out_partial=None):
     A.check(A.lib().sgg_conv2d_fwd_stats(C.byref(g.desc), _p(x), _p(w_fwd), _p(bias), _p(y), _p(partial), _p(ws), g.ws_fwd, _s()), "conv2d_fwd_stats")
     if pr: pr.stop()
     return y, partial
+
+
+def conv_fwd_stats_pair(g: ConvGeom, x, w_fwd, bias, w_fwd2, bias2, nsplit):
+    """conv_fwd_stats over a stacked batch of two networks: images [:nsplit] with (w_fwd, bias), the rest with (w_fwd2, bias2)."""
+    assert tuple(x.shape) == g.x_shape and g.pair_ok and g.stats_chunks > 0 and 0 < nsplit < g.x_shape[0]
+    y = torch.empty(g.y_shape, dtype=x.dtype, device=x.device)
+    partial = torch.empty((g.y_shape[0], g.stats_chunks, g.y_shape[3], 2), dtype=torch.float32, device=x.device)
+    pr = _prof("conv2d_fwd_pair", g)
+    if pr: pr.start()
+    ws = workspace(g.ws_fwd, x.device) if g.ws_fwd else None
+    A.check(A.lib().sgg_conv2d_fwd_stats_pair(C.byref(g.desc), _p(x), _p(w_fwd), _p(bias), _p(w_fwd2), _p(bias2), nsplit, _p(y), _p(partial),
+                                              _p(ws), g.ws_fwd, _s()), "conv2d_fwd_stats_pair")
+    if pr: pr.stop()
+    return y, partial
+
+
+def conv_dgrad_pair(g: ConvGeom, dy, w_dgrad, w_dgrad2, nsplit, addend=None):
+    assert tuple(dy.shape) == g.y_shape and g.pair_ok and 0 < nsplit < g.y_shape[0]
+    assert addend is None or (tuple(addend.shape) == g.x_shape and addend.dtype == dy.dtype)
+    dx = torch.empty(g.x_shape, dtype=dy.dtype, device=dy.device)
+    pr = _prof("conv2d_bwd_data_pair", g)
+    if pr: pr.start()
+    ws = workspace(g.ws_dgrad, dy.device) if g.ws_dgrad else None
+    A.check(A.lib().sgg_conv2d_bwd_data_pair(C.byref(g.desc), _p(dy), _p(w_dgrad), _p(w_dgrad2), nsplit, _p(addend), _p(dx), _p(ws), g.ws_dgrad, _s()),
+            "conv2d_bwd_data_pair")
+    if pr: pr.stop()
+    return dx
 
 
 def conv_dgrad(g: ConvGeom, dy, w_dgrad, addend=None, out_f32=False, out=None):

@@ -554,8 +554,18 @@ class _PairUnit:
         g = ua.geom(x[:n])
         na, nb = ua.name, ub.name
         PA, PB = ua.net.P, ub.net.P
-        xc = torch.empty((2 * n,) + tuple(g.y_shape[1:]), dtype=x.dtype, device=x.device)
         fused_act = A.ACT_NONE if ua.norm else ua.act
+        g2 = ua.geom(x) if ua.kind == "conv" else None     # geometry of the stacked batch
+        if ua.kind == "conv" and ua.norm and g.stats_chunks and FUSE_CONV_IN_STATS and g2.pair_ok:
+            # one launch for both networks (per-image weights): 512 blocks, the second round's halo loads run under the
+            # first round's stores
+            wfa, _ = ua.packed(x.dtype)
+            wfb, _ = ub.packed(x.dtype)
+            xc, part = K.conv_fwd_stats_pair(g2, x, wfa, PA.p(na + "_b"), wfb, PB.p(nb + "_b"), n)
+            y, stats = K.instnorm_fwd_partial_pair(xc, part, PA.p(na + "_g"), PA.p(na + "_beta"), PB.p(nb + "_g"), PB.p(nb + "_beta"), n,
+                                                   residual, ua.net.eps, ua.act, ua.leak)
+            return y, (g, x, xc, stats)
+        xc = torch.empty((2 * n,) + tuple(g.y_shape[1:]), dtype=x.dtype, device=x.device)
         if ua.kind == "conv" and ua.norm and g.stats_chunks and FUSE_CONV_IN_STATS:
             part = torch.empty((2 * n, g.stats_chunks, g.y_shape[3], 2), dtype=torch.float32, device=x.device)
             for u, sl in halves:
@@ -602,6 +612,8 @@ class _PairUnit:
                 u.weight_grad(g, x[sl], dxc[sl])
         if not want_dx:
             return None
+        if ua.kind == "conv" and ua.geom(x).pair_ok:
+            return K.conv_dgrad_pair(ua.geom(x), dxc, ua.packed(x.dtype)[1], ub.packed(x.dtype)[1], n, addend)
         dx = torch.empty((2 * n,) + tuple(g.x_shape[1:]), dtype=dxc.dtype, device=dxc.device)
         for u, sl in halves:
             wf, wd = u.packed(x.dtype)

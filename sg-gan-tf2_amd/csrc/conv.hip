@@ -762,7 +762,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     const int img = mt / tilesH;
     const int h0 = th * 2, w0 = tw * H3_TW;
     const char* const wmat_n = img >= a.nsplit ? a.wmat2 : a.wmat;       // (two networks stacked on the batch: per-image weights)
-    const float* const bias_n = img >= a.nsplit ? a.bias2 : a.bias;
     const bool dbg_clk = SGG_ABLATE_OF(a) == 9 && lid == 0 && tid == 0;
     const int abl = SGG_ABLATE_OF(a) >= 8 ? 0 : SGG_ABLATE_OF(a);    // 8, 9 = full kernel + clock stamps
     if (dbg_clk) { g_dbg_clk[0] = clock64(); g_dbg_clk[1] = wall_clock64(); }
@@ -964,6 +963,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         // pixel-major store order: the four 16-channel groups of a pixel go out back to back, so the 128 bytes a wave
         // writes per pixel merge into whole lines in L2 (channel-group-major order cost +47 MB of HBM fetches per launch:
         // partially written lines are read back)
+        const float* const bias_n = img >= a.nsplit ? a.bias2 : a.bias;      // (picked here, not before the loop: registers)
         float bv[NI][4], s1[NI][4], s2[NI][4];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -1035,6 +1035,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     // with coalesced 16-byte pieces, and each lane then picks its 8-byte (pixel, 4 channels) groups out of LDS.  (Reading
     // them straight from global memory, 32 scattered 8-byte loads per lane, cost +27 us per launch.)  512-byte pixel rows,
     // 16-byte chunk c of pixel p at position c ^ (p & 31): the 16 pixels a ds_read_b64 touches hit 16 different chunks.
+    const float* const bias_n = img >= a.nsplit ? a.bias2 : a.bias;
     if constexpr (STATS == 2) {
         for (int id = wave; id < 128; id += 8) {         // 128 wave-instructions of 2 pixels x 512 B
             const int p = id * 2 + (lane >> 5), pos = lane & 31;

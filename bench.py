@@ -89,41 +89,54 @@ def measured_traffic(kernel):
         return None
 
 
+def measured_in_traffic(algorithmic_bytes):
+    """HBM bytes of the instance-norm apply pass per algorithmic byte (profiles/r02_in_traffic.json: 33.55 MB tensor read + written),
+    scaled to `algorithmic_bytes`; None if not collected."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_in_traffic.json")) as f:
+            return json.load(f)["in_apply_kernel_fwd"]["hbm_bytes_per_launch"] / (2 * 33554432.0) * algorithmic_bytes
+    except Exception:
+        return None
+
+
 class EventProfiler:
     """Times selected launches with HIP events on the stream the kernels are launched on, inside the timed region.
 
-    Events cannot be read back from inside a captured HIP graph (external event nodes abort on this ROCm/PyTorch), so in
-    graph mode the LAST steps of the timed region are dispatched eagerly -- same kernels, same order, same state, and the
-    same throughput (the eager step is GPU-bound too: 205 vs 204 images/s) -- and those are the steps whose launches are
-    timed.  ``mode``: "off", "live" (record), "calibrate" (an EMPTY event pair at the same places, in extra untimed
-    steps: the cost of the pair itself is taken off the spans)."""
-
-    # one launch in N per kernel family is timed: every pair is two marker packets in the launch queue
-    SAMPLE_EVERY = {"res_conv_fwd": 2, "res_conv_dgrad": 6, "res_conv_wgrad": 6, "res_conv_wgrad_pair": 6,
-                    "res_instnorm_fwd": 1, "res_instnorm_fwd_fused_stats": 6}
+    The events ride on the kernel's OWN dispatch packet (libsggan's sgg_time_next_launch -> hipExtLaunchKernel start / stop
+    events), so a span is that kernel's begin-to-end time as the command processor stamps it -- the clock rocprofv3's kernel
+    trace reads -- with no marker packets in the queue and nothing to subtract (round 1 bracketed the call with torch.cuda.Event
+    markers and took an empty pair's cost off; both read the same within 1 %).  For a call that launches helpers too (side-tensor
+    gather, slab reduce, norm finalize) the span is the MAIN kernel only.  NOTE for readers of the rocprofv3 summary of this
+    command: the reference-mode leg at the end of the run (`reference_mode_step`) launches the same kernels on 8 images where the
+    cycle step's paired launches cover 16, so a per-name average mixes the two unless the name says which (the paired
+    instantiations carry PAIR = true as their last template argument).
+    Events cannot be read back from inside a captured HIP graph, so in graph mode the LAST steps of the timed region are
+    dispatched eagerly -- same kernels, same order, same state, same throughput -- and those are the steps whose launches are
+    timed.  ``mode``: "off" or "live"."""
 
     def __init__(self, res_hw=(64, 128)):
         self.records = {}
         self.mode = "off"
         self.res_hw = tuple(res_hw)          # spatial size of the residual blocks (H/4, W/4)
-        self.seen = {}
-        self.empty = []
+        self.unused = 0                      # armed pairs no timed-family launch picked up (a call that took another kernel path)
 
     class _Span:
         def __init__(self, prof, store):
-            self.prof, self.store = prof, store
-            self.s, self.e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            import ctypes
+            from sggan_amd import _abi as A
+            self.prof, self.store, self.A = prof, store, A
+            self.s, self.e = ctypes.c_void_p(), ctypes.c_void_p()
+            A.check(A.lib().sgg_event_create(ctypes.byref(self.s)), "event_create")
+            A.check(A.lib().sgg_event_create(ctypes.byref(self.e)), "event_create")
 
         def start(self):
-            self.s.record()
-            if self.prof.mode == "calibrate":
-                self.e.record()
-                self.prof.empty.append((self.s, self.e))
+            self.A.lib().sgg_time_next_launch(self.s, self.e)
 
         def stop(self):
-            if self.prof.mode == "live":
-                self.e.record()
+            if self.A.lib().sgg_time_next_launch(None, None) == 1:
                 self.store.append((self.s, self.e))
+            else:
+                self.prof.unused += 1
 
     def __call__(self, name, key):
         if self.mode == "off":
@@ -145,30 +158,28 @@ class EventProfiler:
             d = key.desc
             if d.R == 3 and d.C == 256 and d.K == 256 and d.stride == 1 and d.pad_mode == 1:
                 tag = ("res_conv_wgrad_pair", d.R * d.S * d.C, d.K, 2 * d.N * d.Ho * d.Wo)   # two applications, one launch
-        elif name == "instnorm_fwd" and len(key) == 4 and key[3] == 256 and tuple(key[1:3]) == self.res_hw:
-            tag = ("res_instnorm_fwd", key[0] * key[1] * key[2] * key[3])
-        elif name == "instnorm_fwd_partial" and len(key) == 4 and key[3] == 256 and tuple(key[1:3]) == self.res_hw:
-            tag = ("res_instnorm_fwd_fused_stats", key[0] * key[1] * key[2] * key[3])
+        elif name in ("instnorm_fwd", "instnorm_fwd_pair", "instnorm_fwd_partial", "instnorm_fwd_partial_pair"):
+            shape, has_res = key
+            if len(shape) == 4 and shape[3] == 256 and tuple(shape[1:3]) == self.res_hw:
+                # the apply pass: read x (+ the skip tensor in the block's second norm), write y
+                tag = ("res_instnorm_apply_fwd", shape[0] * shape[1] * shape[2] * shape[3], 3 if has_res else 2)
         if tag is None:
-            return None
-        k = self.seen.get(tag, 0)
-        self.seen[tag] = k + 1
-        if k % self.SAMPLE_EVERY.get(tag[0], 6):
             return None
         return self._Span(self, self.records.setdefault(tag, []))
 
-    def overhead_ms(self):
-        # median: an empty pair occasionally straddles a queue hiccup of tens of microseconds
-        return float(np.median([s.elapsed_time(e) for s, e in self.empty])) if self.empty else 0.0
-
     def summary(self):
-        """tag -> (mean span minus the event-pair overhead, samples, raw mean span)"""
-        out, ov = {}, self.overhead_ms()
+        """tag -> (mean kernel time in ms, samples); call after a device synchronize"""
+        import ctypes
+        from sggan_amd import _abi as A
+        out = {}
         for tag, evs in self.records.items():
-            if not evs:
-                continue
-            ms = [s.elapsed_time(e) for s, e in evs]
-            out[tag] = (max(float(np.mean(ms)) - ov, 1e-6), len(ms), float(np.mean(ms)))
+            ms = []
+            for s, e in evs:
+                v = ctypes.c_float()
+                A.check(A.lib().sgg_event_elapsed_ms(s, e, ctypes.byref(v)), "event_elapsed")
+                ms.append(v.value)
+            if ms:
+                out[tag] = (float(np.mean(ms)), len(ms))
         return out
 
 
@@ -320,12 +331,6 @@ def main():
         model.train_step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if not a.no_kernel_timing:                    # calibration: two untimed eager steps (every rank: the steps all-reduce) with
-        model.use_graph = False                   # empty event pairs at the sampled launches (rank 0)
-        prof.mode = "calibrate" if timing else "off"
-        for _ in range(2):
-            model.train_step()
-        barrier()
     prof.mode = "off"
     model.use_graph = bool(a.graph)
     if dist is not None:
@@ -360,35 +365,48 @@ def main():
         }
         summ = prof.summary()
         kt = {}
-        for tag, (ms, n, raw) in summ.items():
+        esz = 2 if a.dtype == "bf16" else 4
+        for tag, (ms, n) in summ.items():
             if tag[0].startswith("res_conv"):
                 fl = 2.0 * tag[1] * tag[2] * tag[3]
-                kt[tag[0]] = {"avg_ms": ms, "avg_ms_raw_span": raw, "launches": n, "tflops": fl / (ms * 1e-3) / 1e12, "gflop_per_launch": fl / 1e9}
+                kt[tag[0]] = {"avg_ms": ms, "launches": n, "tflops": fl / (ms * 1e-3) / 1e12, "gflop_per_launch": fl / 1e9}
             else:
-                passes = 2 if tag[0].endswith("fused_stats") else 3      # fused: statistics came from the conv epilogue
-                by = passes * tag[1] * (2 if a.dtype == "bf16" else 4)  # (1 or 2) reads + 1 write of the tensor
-                kt[tag[0]] = {"avg_ms": ms, "avg_ms_raw_span": raw, "launches": n, "gbs": by / (ms * 1e-3) / 1e9, "mbytes_per_launch": by / 1e6}
+                by = tag[2] * tag[1] * esz                               # (1 or 2) reads + 1 write of the tensor
+                k = kt.setdefault(tag[0], {"ms_total": 0.0, "launches": 0, "bytes_total": 0.0})
+                k["ms_total"] += ms * n; k["launches"] += n; k["bytes_total"] += by * n
+        for k in kt.values():
+            if "bytes_total" in k:
+                k["avg_ms"] = k["ms_total"] / k["launches"]
+                k["gbs"] = k["bytes_total"] / (k["ms_total"] * 1e-3) / 1e9
+                k["mbytes_per_launch"] = k.pop("bytes_total") / k["launches"] / 1e6
+                k.pop("ms_total")
+        how = ("HIP events on the kernel's own dispatch packet (sgg_time_next_launch -> hipExtLaunchKernel start/stop events) on the "
+               "launch stream, every launch of this kernel inside the timed region"
+               + (f" (its last {eager_tail} steps, which are dispatched eagerly: events cannot be read back from inside a replayed HIP graph)" if a.graph else "")
+               + "; helper launches of the same call (side-tensor gather, slab reduce, norm finalize) are not in the span")
         if "res_conv_fwd" in kt:
             k = kt["res_conv_fwd"]
+            t8 = measured_traffic("res_conv_fwd")                         # PMC passes ran the 8-image launch (77.3 GFLOP)
             line["roofline"] = {"bound": "mfma", "kernel": "conv3x3_halo_gemm_kernel<FWD, STATS> (bf16, 256x256 tile, 8 waves, input halo resident in LDS; 3x3 C=256 residual-block conv; "
                                           "in the cycle step one launch covers the stacked images of both generators -- gflop_per_launch says how many; the timed "
                                           "launch also computes the following instance norm's per-channel sums in its epilogue, ~4 us, not counted in the FLOPs)",
                                 "achieved": k["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                "frac": k["tflops"] / PEAK_BF16_TFLOPS, "traffic": measured_traffic("res_conv_fwd"),
+                                "frac": k["tflops"] / PEAK_BF16_TFLOPS,
+                                "traffic": None if t8 is None else t8 * k["gflop_per_launch"] / 77.309411328,
+                                "traffic_note": "FETCH_SIZE (doubled, gfx950) + WRITE_SIZE of the 8-image launch (profiles/r02_traffic.json), scaled to this launch's image count",
                                 "avg_launch_ms": k["avg_ms"], "launches_timed": k["launches"], "gflop_per_launch": k["gflop_per_launch"],
-                                "event_pair_overhead_ms": prof.overhead_ms(), "avg_span_ms_raw": k["avg_ms_raw_span"],
-                                "timing": ("HIP events on the launch stream around 1 launch in 2 inside the timed region"
-                                           + (f" (its last {eager_tail} steps, which are dispatched eagerly: events cannot be read back from inside a replayed HIP graph)" if a.graph else "")
-                                           + "; the cost of an empty event pair at the same places (measured in 2 extra untimed steps) is subtracted")}
+                                "timing": how}
         else:
             line["roofline"] = None
-        if "res_instnorm_fwd" in kt:
-            k = kt["res_instnorm_fwd"]
+        if "res_instnorm_apply_fwd" in kt:
+            k = kt["res_instnorm_apply_fwd"]
             line["roofline_instnorm"] = {"bound": "hbm", "achieved": k["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                         "frac": k["gbs"] / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": k["avg_ms"],
-                                         "note": "unfused instance norm on a (N,H/4,W/4,256) tensor (after the stride-2 conv c3): 3 launches (partial stats, "
-                                                 "finalize, apply); algorithmic bytes = 2 reads + 1 write.  The residual blocks' norms take their "
-                                                 "statistics from the conv epilogue (kernels.res_instnorm_fwd_fused_stats: finalize + apply)"}
+                                         "frac": k["gbs"] / PEAK_HBM_GBS, "traffic": measured_in_traffic(k["mbytes_per_launch"] * 1e6),
+                                         "avg_launch_ms": k["avg_ms"], "launches_timed": k["launches"], "mbytes_per_launch": k["mbytes_per_launch"],
+                                         "note": "in_apply_kernel forward on the residual blocks' (N,H/4,W/4,256) tensors: normalise + ReLU (read, write) and "
+                                                 "normalise + skip add (2 reads, write), averaged over both; the statistics come from the conv epilogue "
+                                                 "(finalize launch not in the span); traffic = FETCH_SIZE (doubled) + WRITE_SIZE of the kernel's read+write "
+                                                 "form per tensor byte (profiles/r02_in_traffic.json), scaled to the timed mix"}
         line["kernels"] = kt
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_cycle(a.height, a.width, 19) if a.mode == "cycle" else cpu_baseline(a.height, a.width, 19)

@@ -55,6 +55,20 @@ typedef struct sgg_conv_desc {
 int sgg_version(void);
 const char* sgg_strerror(int status);
 
+/* ---- measurement hooks (bench.py's roofline leg; not part of the drop-in surface) -----------------------------------
+ * sgg_time_next_launch(start, stop) arms one pair of HIP events for the calling host thread: the next launch of a timed
+ * kernel family's MAIN kernel made by that thread -- the 3x3 halo GEMMs (sgg_conv2d_fwd* / _bwd_data* on the
+ * residual-block shape), the all-taps weight gradient (sgg_conv2d_bwd_weight*), the instance-norm apply pass
+ * (sgg_instnorm_fwd*) -- carries them on its own dispatch packet (hipExtLaunchKernel), so sgg_event_elapsed_ms gives that
+ * kernel's begin-to-end time on the launch stream, as rocprofv3's kernel trace does.  Helper launches of the same call
+ * (side-tensor gather, slab reduce, norm finalize) are not included.  (NULL, NULL) disarms and returns 1 if the armed
+ * pair was consumed by a launch, 0 if not; arming returns the same for the previous pair.  Not for use while a stream is
+ * being captured. */
+int sgg_event_create(void** ev);
+int sgg_event_destroy(void* ev);
+int sgg_event_elapsed_ms(void* start, void* stop, float* ms);
+int sgg_time_next_launch(void* start, void* stop);
+
 /* ---- weights -------------------------------------------------------------------
  * Keras kernel (HWIO f32, module.py:211 etc.; for Conv2DTranspose the (kh,kw,out,in)
  * kernel of module.py:254,258 IS the HWIO kernel of the equivalent conv) ->

@@ -37,6 +37,10 @@ _dp = C.POINTER(ConvDesc)
 SIGNATURES = {
     "sgg_version": (_i, []),
     "sgg_strerror": (C.c_char_p, [_i]),
+    "sgg_event_create": (_i, [C.POINTER(C.c_void_p)]),
+    "sgg_event_destroy": (_i, [_vp]),
+    "sgg_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
+    "sgg_time_next_launch": (_i, [_vp, _vp]),
     "sgg_pack_conv_weights": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sgg_pack_conv_weights_batch": (_i, [_vp, _i, _i64, _i, _vp]),
     "sgg_conv2d_fwd_workspace": (_sz, [_dp]),

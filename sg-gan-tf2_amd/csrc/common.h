@@ -1,8 +1,10 @@
 // common.h -- shared device/host helpers for libsggan.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <atomic>
+#include <type_traits>
 #include "../../include/sggan.h"
 
 typedef __bf16 bf16;
@@ -60,6 +62,28 @@ __device__ inline float act_apply(float v, int act, float leak) {
         default: return v;
     }
 }
+// Epilogues: the activation code is a launch-wide constant, so it is tested ONCE and the per-element code is compiled per
+// activation (act_apply's switch inside an unrolled store loop put branches -- tanhf is a call-sized body -- between every
+// pair of stores and made hipcc drain vmcnt(0) after each addend load: 12 us of a 141 us GEMM).
+template <int ACT> __device__ inline float act_apply_c(float v, float leak) {
+    if constexpr (ACT == SGG_ACT_RELU) return v > 0.f ? v : 0.f;
+    else if constexpr (ACT == SGG_ACT_LRELU) return v > 0.f ? v : leak * v;
+    else if constexpr (ACT == SGG_ACT_TANH) return tanhf(v);
+    else return v;
+}
+template <typename F> __device__ inline void act_dispatch(int act, F&& f) {   // f(std::integral_constant<int, ACT>{})
+    switch (act) {
+        case SGG_ACT_RELU: f(std::integral_constant<int, SGG_ACT_RELU>{}); break;
+        case SGG_ACT_LRELU: f(std::integral_constant<int, SGG_ACT_LRELU>{}); break;
+        case SGG_ACT_TANH: f(std::integral_constant<int, SGG_ACT_TANH>{}); break;
+        default: f(std::integral_constant<int, SGG_ACT_NONE>{}); break;
+    }
+}
+template <int ACT> __device__ inline float act_grad_c(float pre, float leak) {
+    if constexpr (ACT == SGG_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
+    else if constexpr (ACT == SGG_ACT_LRELU) return pre > 0.f ? 1.f : leak;
+    else return 1.f;
+}
 // derivative evaluated from the pre-activation (relu/lrelu) -- sign only
 __device__ inline float act_grad_from_pre(float pre, int act, float leak) {
     switch (act) {
@@ -112,6 +136,23 @@ static inline int sgg_lds_attr(const void* kern, int bytes, std::atomic<uint64_t
         int sgg_attr_rc_ = sgg_lds_attr((const void*)(kern), (int)(bytes), sgg_attr_done_); \
         if (sgg_attr_rc_) return sgg_attr_rc_;                                           \
     } while (0)
+
+// Measurement hook (sgg_time_next_launch, include/sggan.h): a host thread may arm ONE pair of HIP events; the next launch that
+// goes through sgg_launch_timed -- the main kernel of a timed family: the halo GEMMs, the all-taps weight gradient, the
+// instance-norm apply pass -- carries them ON ITS OWN DISPATCH PACKET (hipExtLaunchKernel), so their timestamps are the
+// kernel's begin and end as the command processor records them, the same clock rocprofv3's kernel trace reads.
+struct SggTimedLaunch { hipEvent_t start = nullptr, stop = nullptr; int consumed = 0; };
+SggTimedLaunch& sgg_timed_launch();                     // thread-local (misc.hip)
+template <typename F, typename... Args>
+static inline void sgg_launch_timed(F kern, dim3 grid, dim3 block, unsigned lds, hipStream_t s, Args... args) {
+    SggTimedLaunch& t = sgg_timed_launch();
+    if (t.start && !t.consumed) {
+        hipExtLaunchKernelGGL(kern, grid, block, lds, s, t.start, t.stop, 0, args...);
+        t.consumed = 1;
+    } else {
+        hipLaunchKernelGGL(kern, grid, block, lds, s, args...);
+    }
+}
 
 // kernel-selection switches (defaults = the shipped configuration); see sgg_config() in conv.hip
 struct SggConfig {

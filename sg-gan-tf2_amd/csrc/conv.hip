@@ -20,6 +20,7 @@
 // the parity path, consuming the same 16-byte fragments with a k-permutation that A and B share).
 // The weight fragment is the MFMA A operand and the pixel fragment the B operand, so the accumulator holds
 // D[cout][pixel]: each lane owns 4 consecutive output channels of one pixel = one 8/16-byte NHWC store.
+#include <type_traits>
 #include "common.h"
 #include <stdlib.h>
 
@@ -653,43 +654,53 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) bv[i][e] = (a.bias && a.ksplit <= 1 && dc < DC) ? a.bias[dc + e] : 0.f;
     }
+    // uniform conditions (split-K, activation, addend) are tested once, outside the unrolled store loops
+    auto epilogue = [&](auto mode_c) {
+        constexpr int EP = decltype(mode_c)::value;               // -1: split-K partial; else 2 * ACT + (addend ? 1 : 0)
 #pragma unroll
-    for (int j = 0; j < MI; ++j) {
-        int m = m0 + wm * WM + j * 16 + frow;
-        if (m >= M) continue;
-        size_t dpix;
-        if (MODE == MODE_FWD || st == 1) dpix = (size_t)m;       // stride 1: destination pixel index == GEMM row
-        else {
-            int n, h, w;
-            decode(m, n, h, w);
-            dpix = ((size_t)n * a.H + h) * a.W + w;
+        for (int j = 0; j < MI; ++j) {
+            int m = m0 + wm * WM + j * 16 + frow;
+            if (m >= M) continue;
+            size_t dpix;
+            if (MODE == MODE_FWD || st == 1) dpix = (size_t)m;       // stride 1: destination pixel index == GEMM row
+            else {
+                int n, h, w;
+                decode(m, n, h, w);
+                dpix = ((size_t)n * a.H + h) * a.W + w;
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                int dc = n0 + wn * WN + i * 16 + fq * 4;
+                if (dc >= DC) continue;
+                if constexpr (EP < 0) {                              // f32 partial; bias/activation are applied by the reducer
+                    float* o = a.partial + ((size_t)blockIdx.y * a.pdst + dpix) * DC + dc;
+                    *reinterpret_cast<f32x4*>(o) = acc[i][j];
+                } else {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_apply_c<EP / 2>(acc[i][j][e] + bv[i][e], a.leak);
+                    if constexpr (EP & 1) {                          // + skip-connection gradient (module.py:217 backward)
+                        const T* ad = reinterpret_cast<const T*>(a.addend) + dpix * DC + dc;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)ad[e];
+                    }
+                    T* o = reinterpret_cast<T*>(a.dst) + dpix * DC + dc;
+                    if constexpr (sizeof(T) == 2) {
+                        bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                        *reinterpret_cast<bf16x4*>(o) = pk;
+                    } else {
+                        *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+                    }
+                }
+            }
         }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            int dc = n0 + wn * WN + i * 16 + fq * 4;
-            if (dc >= DC) continue;
-            if (a.ksplit > 1) {                                  // f32 partial; bias/activation are applied by the reducer
-                float* o = a.partial + ((size_t)blockIdx.y * a.pdst + dpix) * DC + dc;
-                *reinterpret_cast<f32x4*>(o) = acc[i][j];
-                continue;
-            }
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[i][j][e] + bv[i][e], a.act, a.leak);
-            if (a.addend) {                                      // + skip-connection gradient (module.py:217 backward)
-                const T* ad = reinterpret_cast<const T*>(a.addend) + dpix * DC + dc;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)ad[e];
-            }
-            T* o = reinterpret_cast<T*>(a.dst) + dpix * DC + dc;
-            if constexpr (sizeof(T) == 2) {
-                bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                *reinterpret_cast<bf16x4*>(o) = pk;
-            } else {
-                *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
-            }
-        }
-    }
+    };
+    if (a.ksplit > 1) epilogue(std::integral_constant<int, -1>{});
+    else act_dispatch(a.act, [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;
+        if (a.addend) epilogue(std::integral_constant<int, 2 * ACT + 1>{});
+        else epilogue(std::integral_constant<int, 2 * ACT>{});
+    });
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -726,7 +737,9 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
 //   columns: the two pixels per tile row in columns 1 / W-2 read their gather row per tap from a small LDS patch
 //            (2 x 2 x 9 rows per chunk, from a.fold's first part, which holds the complete mirrored sums for those
 //            pixels) through a per-lane address select in the first / last pixel fragment.
-template <int MODE, bool FOLD, int STATS = 0>        // STATS: 0 none, 1 forward norm sums, 2 backward norm sums
+// PAIR: two networks of one shape on a stacked batch, images >= a.nsplit take the second weight set (a compile-time flag so
+// that the launches of the paired cycle step show under their own name in a kernel trace: they cover twice the images)
+template <int MODE, bool FOLD, int STATS = 0, bool PAIR = false>   // STATS: 0 none, 1 forward norm sums, 2 backward norm sums
 __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     constexpr int BN = 256, WGM = 2, WGN = 4, WM = 128, WN = 64, MI = 8, NI = 4, BKB = 128, KK = 2;
     constexpr int QA = 4;                              // weight rows per thread per tile (8 waves x 8 rows x 4)
@@ -761,7 +774,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     const int th = mt % tilesH;
     const int img = mt / tilesH;
     const int h0 = th * 2, w0 = tw * H3_TW;
-    const char* const wmat_n = img >= a.nsplit ? a.wmat2 : a.wmat;       // (two networks stacked on the batch: per-image weights)
+    const char* const wmat_n = PAIR && img >= a.nsplit ? a.wmat2 : a.wmat;
     const bool dbg_clk = SGG_ABLATE_OF(a) == 9 && lid == 0 && tid == 0;
     const int abl = SGG_ABLATE_OF(a) >= 8 ? 0 : SGG_ABLATE_OF(a);    // 8, 9 = full kernel + clock stamps
     if (dbg_clk) { g_dbg_clk[0] = clock64(); g_dbg_clk[1] = wall_clock64(); }
@@ -873,7 +886,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         // issuing its share at the head of the tile, all eight sat in issue stalls for that long with the matrix pipes idle
         // (tools/halo_phases.py).  Now waves 4-7 issue ALL the DMAs while waves 0-3 -- their SIMD partners -- go straight to
         // their MFMAs.  (Not the same as splitting each wave's issue in time: waves 4-7 issuing their own share half way
-        // through the tile measured 7 % slower.)
+        // through the tile measured 7 % slower; waves 0-3 issuing the halo rows, or 2-4 of the 8 weight DMAs per SIMD pair,
+        // AFTER their MFMAs -- in the ~1 000 cycles they wait at the barrier -- measured 2-3 % slower.)
         if (abl == 0 || abl == 2) {
             const int vw = wave & 3;
             if ((wave >> 2) == H3_ISSUER_HALF) {           // the weight tile: 8 DMA instructions per issuer wave and tile
@@ -963,7 +977,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         // pixel-major store order: the four 16-channel groups of a pixel go out back to back, so the 128 bytes a wave
         // writes per pixel merge into whole lines in L2 (channel-group-major order cost +47 MB of HBM fetches per launch:
         // partially written lines are read back)
-        const float* const bias_n = img >= a.nsplit ? a.bias2 : a.bias;      // (picked here, not before the loop: registers)
+        const float* const bias_n = PAIR && img >= a.nsplit ? a.bias2 : a.bias;   // (picked here, not before the loop: registers)
         float bv[NI][4], s1[NI][4], s2[NI][4];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -971,36 +985,82 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { bv[i][e] = (bias_n && dc < DC) ? bias_n[dc + e] : 0.f; s1[i][e] = s2[i][e] = 0.f; }
         }
+        // PLAIN path (every call of the step: no activation, bf16 result, bf16 or no addend): the uniform conditions are tested
+        // once, and the skip-gradient addend's 32 loads per lane are all issued before the first store -- the fragment registers
+        // are dead here.  (With the tests inside the unrolled loops every load was followed by s_waitcnt vmcnt(0): 32 dependent
+        // round trips at the tail of a grid that has nothing else to overlap them with.)
+        const bool plain = a.act == SGG_ACT_NONE && !(MODE != MODE_FWD && (a.dst_f32 || a.addend_f32));
+        if (plain) {
+            auto run = [&](auto has_add) {
+                constexpr bool ADD = decltype(has_add)::value;
+                const size_t e0 = (prow + frow) * DC + n0 + wn * WN + fq * 4;      // element (pixel j = 0, group i = 0) of this lane
+                const size_t ej = (size_t)16 * DC;
+                bf16x4 adv[MI][NI];
+                if constexpr (ADD) {
 #pragma unroll
-        for (int j = 0; j < MI; ++j) {
-            const size_t dpix = prow + j * 16 + frow;
+                    for (int j = 0; j < MI; ++j)
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int dc = n0 + wn * WN + i * 16 + fq * 4;
-                if (dc >= DC) continue;
-                float v[4];
+                        for (int i = 0; i < NI; ++i) {
+                            const int dc = n0 + wn * WN + i * 16 + fq * 4;
+                            adv[j][i] = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+                            if (dc < DC) adv[j][i] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(a.addend) + e0 + j * ej + i * 16);
+                        }
+                }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[i][j][e] + bv[i][e], a.act, a.leak);
-                if (a.addend) {
-                    if (MODE != MODE_FWD && a.addend_f32) {
-                        const f32x4 ad = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.addend) + dpix * DC + dc);
+                for (int j = 0; j < MI; ++j) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += ad[e];
-                    } else {
-                        const bf16* ad = reinterpret_cast<const bf16*>(a.addend) + dpix * DC + dc;
+                    for (int i = 0; i < NI; ++i) {
+                        const int dc = n0 + wn * WN + i * 16 + fq * 4;
+                        if (dc >= DC) continue;
+                        float v[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)ad[e];
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bv[i][e];
+                        if constexpr (ADD) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)adv[j][i][e];
+                        }
+                        bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.dst) + e0 + j * ej + i * 16) = pk;
+                        if (STATS == 1) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { const float vr = (float)pk[e]; s1[i][e] += vr; s2[i][e] += vr * vr; }
+                        }
                     }
                 }
-                if (MODE != MODE_FWD && a.dst_f32) {      // mixed mode: the data gradient stays f32 on its way to the next norm backward
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.dst) + dpix * DC + dc) = (f32x4){v[0], v[1], v[2], v[3]};
-                    continue;
-                }
-                bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.dst) + dpix * DC + dc) = pk;
-                if (STATS == 1) {
+            };
+            if (MODE != MODE_FWD && a.addend) run(std::true_type{}); else run(std::false_type{});
+        } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float vr = (float)pk[e]; s1[i][e] += vr; s2[i][e] += vr * vr; }
+            for (int j = 0; j < MI; ++j) {
+                const size_t dpix = prow + j * 16 + frow;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int dc = n0 + wn * WN + i * 16 + fq * 4;
+                    if (dc >= DC) continue;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[i][j][e] + bv[i][e], a.act, a.leak);
+                    if (a.addend) {
+                        if (MODE != MODE_FWD && a.addend_f32) {
+                            const f32x4 ad = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.addend) + dpix * DC + dc);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += ad[e];
+                        } else {
+                            const bf16* ad = reinterpret_cast<const bf16*>(a.addend) + dpix * DC + dc;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)ad[e];
+                        }
+                    }
+                    if (MODE != MODE_FWD && a.dst_f32) {      // mixed mode: the data gradient stays f32 on its way to the next norm backward
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.dst) + dpix * DC + dc) = (f32x4){v[0], v[1], v[2], v[3]};
+                        continue;
+                    }
+                    bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.dst) + dpix * DC + dc) = pk;
+                    if (STATS == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float vr = (float)pk[e]; s1[i][e] += vr; s2[i][e] += vr * vr; }
+                    }
                 }
             }
         }
@@ -1035,7 +1095,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     // with coalesced 16-byte pieces, and each lane then picks its 8-byte (pixel, 4 channels) groups out of LDS.  (Reading
     // them straight from global memory, 32 scattered 8-byte loads per lane, cost +27 us per launch.)  512-byte pixel rows,
     // 16-byte chunk c of pixel p at position c ^ (p & 31): the 16 pixels a ds_read_b64 touches hit 16 different chunks.
-    const float* const bias_n = img >= a.nsplit ? a.bias2 : a.bias;
+    const float* const bias_n = a.bias;                                       // (STATS 2 has no paired form)
     if constexpr (STATS == 2) {
         for (int id = wave; id < 128; id += 8) {         // 128 wave-instructions of 2 pixels x 512 B
             const int p = id * 2 + (lane >> 5), pos = lane & 31;
@@ -1266,29 +1326,36 @@ __global__ __launch_bounds__(512) void deconv_s2_halo_kernel(ConvArgs a, int tot
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bv[i][e] = a.bias ? a.bias[cur.n0 + i * 16 + fq * 4 + e] : 0.f;
+            act_dispatch(a.act, [&](auto act_c) {
+                constexpr int ACT = decltype(act_c)::value;
+                auto store_tile = [&](auto add_c) {
+                    constexpr bool ADD = decltype(add_c)::value;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int h = 2 * (cur.i0 + wave) + (c >> 1);
+                    for (int c = 0; c < 4; ++c) {
+                        const int h = 2 * (cur.i0 + wave) + (c >> 1);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int w = 2 * (cur.j0 + j * 16 + frow) + (c & 1);
-                    const size_t dpix = ((size_t)cur.img * a.H + h) * a.W + w;
+                        for (int j = 0; j < 2; ++j) {
+                            const int w = 2 * (cur.j0 + j * 16 + frow) + (c & 1);
+                            const size_t dpix = ((size_t)cur.img * a.H + h) * a.W + w;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int dc = cur.n0 + i * 16 + fq * 4;
-                        float v[4];
+                            for (int i = 0; i < 4; ++i) {
+                                const int dc = cur.n0 + i * 16 + fq * 4;
+                                float v[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[c][j][i][e] + bv[i][e], a.act, a.leak);
-                        if (a.addend) {
-                            const bf16* ad = reinterpret_cast<const bf16*>(a.addend) + dpix * DC + dc;
+                                for (int e = 0; e < 4; ++e) v[e] = act_apply_c<ACT>(acc[c][j][i][e] + bv[i][e], a.leak);
+                                if constexpr (ADD) {
+                                    const bf16* ad = reinterpret_cast<const bf16*>(a.addend) + dpix * DC + dc;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += (float)ad[e];
+                                    for (int e = 0; e < 4; ++e) v[e] += (float)ad[e];
+                                }
+                                bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                                *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.dst) + dpix * DC + dc) = pk;
+                            }
                         }
-                        bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.dst) + dpix * DC + dc) = pk;
                     }
-                }
-            }
+                };
+                if (a.addend) store_tile(std::true_type{}); else store_tile(std::false_type{});
+            });
             cur = nxt; ++tcur; chunk = 0;
         } else ++chunk;
     }
@@ -1326,14 +1393,14 @@ static bool halo3_ok(const ConvArgs& a, int mode, bool is_bf16) {
     return mode == MODE_FWD || mode == MODE_DGRAD;
 }
 
-template <int MODE, bool FOLD, int STATS = 0>
+template <int MODE, bool FOLD, int STATS = 0, bool PAIR = false>
 static int launch_halo3(const ConvArgs& a, hipStream_t s) {
-    auto kern = conv3x3_halo_gemm_kernel<MODE, FOLD, STATS>;
+    auto kern = conv3x3_halo_gemm_kernel<MODE, FOLD, STATS, PAIR>;
     constexpr int lds = FOLD ? H3_LDS_FOLD : H3_LDS;
     SGG_LDS_ATTR(kern, lds);
     const int DC = MODE == MODE_FWD ? a.K : a.C;
     const int64_t blocks = (int64_t)a.N * (a.H / 2) * (a.W / H3_TW) * ((DC + 255) / 256);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, a);
+    sgg_launch_timed(kern, dim3((unsigned)blocks), dim3(512), (unsigned)lds, s, a);
     return sgg_check_launch();
 }
 
@@ -1494,18 +1561,24 @@ __global__ __launch_bounds__(512) void conv_halo_fwd_kernel(ConvArgs a, int flip
     // D[cout = 4*fq + e][pixel = frow]
     const int dc = fq * 4;
     if (dc < a.K) {
+        float bv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int y = y0 + 2 * wave + (j >> 1), x = x0 + (j & 1) * 16 + frow;
-            float v[4];
+        for (int e = 0; e < 4; ++e) bv[e] = a.bias ? a.bias[dc + e] : 0.f;
+        act_dispatch(a.act, [&](auto act_c) {
+            constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[j][e] + (a.bias ? a.bias[dc + e] : 0.f), a.act, a.leak);
-            T* o = reinterpret_cast<T*>(a.dst) + (((size_t)n * a.H + y) * a.W + x) * a.K + dc;
-            if constexpr (sizeof(T) == 2) {
-                bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                *reinterpret_cast<bf16x4*>(o) = pk;
-            } else *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
-        }
+            for (int j = 0; j < 4; ++j) {
+                const int y = y0 + 2 * wave + (j >> 1), x = x0 + (j & 1) * 16 + frow;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_apply_c<ACT>(acc[j][e] + bv[e], a.leak);
+                T* o = reinterpret_cast<T*>(a.dst) + (((size_t)n * a.H + y) * a.W + x) * a.K + dc;
+                if constexpr (sizeof(T) == 2) {
+                    bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    *reinterpret_cast<bf16x4*>(o) = pk;
+                } else *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+            }
+        });
     }
 }
 
@@ -1642,8 +1715,12 @@ __global__ __launch_bounds__(512) void conv7_narrow_out_kernel(N7Args a) {
         float v = 0.f;
 #pragma unroll
         for (int sc = 0; sc < 7; ++sc) v += Z[(co * 7 + sc) * N7_ZP + lane];
-        o[co] = (co < a.K) ? act_apply(v + (a.bias ? a.bias[co] : 0.f), a.act, a.leak) : 0.f;
+        o[co] = (co < a.K) ? v + (a.bias ? a.bias[co] : 0.f) : 0.f;
     }
+    act_dispatch(a.act, [&](auto act_c) {
+#pragma unroll
+        for (int co = 0; co < 3; ++co) if (co < a.K) o[co] = act_apply_c<decltype(act_c)::value>(o[co], a.leak);
+    });
     if (y < a.Ho && x < a.Wo) {
         const size_t pix = ((size_t)n * a.Ho + y) * a.Wo + x;
         if (a.dst_f32) {
@@ -2293,23 +2370,31 @@ __global__ __launch_bounds__(512) void conv_halo_narrow_in_kernel(ConvArgs a, in
                 }
             }
         }
+        float bv[4][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int y = y0 + 2 * wave + (j >> 1), x = x0 + (j & 1) * 16 + frow;
-            const size_t dpix = ((size_t)n * a.H + y) * a.W + x;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int dc = i * 16 + fq * 4;
-                float v[4];
+            for (int e = 0; e < 4; ++e) bv[i][e] = a.bias ? a.bias[i * 16 + fq * 4 + e] : 0.f;
+        act_dispatch(a.act, [&](auto act_c) {
+            constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[i][j][e] + (a.bias ? a.bias[dc + e] : 0.f), a.act, a.leak);
-                T* o = reinterpret_cast<T*>(a.dst) + dpix * DCH + dc;
-                if constexpr (sizeof(T) == 2) {
-                    bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                    *reinterpret_cast<bf16x4*>(o) = pk;
-                } else *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+            for (int j = 0; j < 4; ++j) {
+                const int y = y0 + 2 * wave + (j >> 1), x = x0 + (j & 1) * 16 + frow;
+                const size_t dpix = ((size_t)n * a.H + y) * a.W + x;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int dc = i * 16 + fq * 4;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_apply_c<ACT>(acc[i][j][e] + bv[i][e], a.leak);
+                    T* o = reinterpret_cast<T*>(a.dst) + dpix * DCH + dc;
+                    if constexpr (sizeof(T) == 2) {
+                        bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                        *reinterpret_cast<bf16x4*>(o) = pk;
+                    } else *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+                }
             }
-        }
+        });
     }
 }
 
@@ -2889,7 +2974,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial
         int c = (int)((i * 4) % DC);
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_apply(s4[e] + (bias ? bias[c + e] : 0.f), act, leak);
+        for (int e = 0; e < 4; ++e) v[e] = s4[e] + (bias ? bias[c + e] : 0.f);
+        act_dispatch(act, [&](auto act_c) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_apply_c<decltype(act_c)::value>(v[e], leak);
+        });
         if (addend) {
             const T* ad = reinterpret_cast<const T*>(addend) + i * 4;
 #pragma unroll
@@ -2949,10 +3038,16 @@ static int launch_gemm(const ConvArgs& a, hipStream_t s) {
     if constexpr (MODE != MODE_BORDER && sizeof(T) == 2) {
         if (halo3_ok(a, MODE, true)) {
             if constexpr (MODE == MODE_DGRAD) {
-                if (a.reflect) return a.stats ? launch_halo3<MODE_DGRAD, true, 2>(a, s) : launch_halo3<MODE_DGRAD, true>(a, s);
+                const bool pair = a.wmat2 != nullptr;
+                if (pair && a.stats) return SGG_EUNSUPPORTED;
+                if (a.reflect) return a.stats ? launch_halo3<MODE_DGRAD, true, 2>(a, s) : pair ? launch_halo3<MODE_DGRAD, true, 0, true>(a, s) : launch_halo3<MODE_DGRAD, true>(a, s);
                 if (a.stats) return launch_halo3<MODE_DGRAD, false, 2>(a, s);
+                if (pair) return launch_halo3<MODE_DGRAD, false, 0, true>(a, s);
             }
-            if constexpr (MODE == MODE_FWD) { if (a.stats) return launch_halo3<MODE_FWD, false, 1>(a, s); }
+            if constexpr (MODE == MODE_FWD) {
+                if (a.wmat2) return a.stats ? launch_halo3<MODE_FWD, false, 1, true>(a, s) : launch_halo3<MODE_FWD, false, 0, true>(a, s);
+                if (a.stats) return launch_halo3<MODE_FWD, false, 1>(a, s);
+            }
             return launch_halo3<MODE, false>(a, s);
         }
     }
@@ -3444,7 +3539,7 @@ static int run_w9(const sgg_conv_desc* d, const void* x, const void* dy, const v
     w.tiles = w9_tiles(d) * (x2 ? 2 : 1);
     w.tiles_per_split = (w.tiles + sp - 1) / sp;
     SGG_LDS_ATTR(conv3x3_wgrad_halo_kernel, 2 * W9_STAGE);
-    hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel, dim3((unsigned)(sp * (d->C / 64) * (d->K / 128))), dim3(512), 2 * W9_STAGE, s, w);
+    sgg_launch_timed(conv3x3_wgrad_halo_kernel, dim3((unsigned)(sp * (d->C / 64) * (d->K / 128))), dim3(512), (unsigned)(2 * W9_STAGE), s, w);
     int rc9 = sgg_check_launch();
     if (rc9) return rc9;
     int64_t total9 = (int64_t)9 * Cr * (d->K / 4);

@@ -419,9 +419,36 @@ static inline int grid_for(int64_t n, int cap = 4096) {
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
+SggTimedLaunch& sgg_timed_launch() {
+    static thread_local SggTimedLaunch t;
+    return t;
+}
+
 extern "C" {
 
 int sgg_version(void) { return SGG_VERSION; }
+
+// ---- measurement hooks (bench.py)
+int sgg_event_create(void** ev) {
+    if (!ev) return SGG_EINVAL;
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return SGG_ELAUNCH; }
+    *ev = (void*)e;
+    return SGG_OK;
+}
+int sgg_event_destroy(void* ev) { return ev && hipEventDestroy((hipEvent_t)ev) == hipSuccess ? SGG_OK : SGG_EINVAL; }
+int sgg_event_elapsed_ms(void* start, void* stop, float* ms) {
+    if (!start || !stop || !ms) return SGG_EINVAL;
+    if (hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) { (void)hipGetLastError(); return SGG_ELAUNCH; }
+    return SGG_OK;
+}
+int sgg_time_next_launch(void* start, void* stop) {
+    SggTimedLaunch& t = sgg_timed_launch();
+    if ((start == nullptr) != (stop == nullptr)) return SGG_EINVAL;
+    const int consumed = t.consumed;
+    t.start = (hipEvent_t)start; t.stop = (hipEvent_t)stop; t.consumed = 0;
+    return consumed;                                     // disarming (NULL, NULL) tells whether the armed pair was used: 1 / 0
+}
 
 const char* sgg_strerror(int status) {
     switch (status) {

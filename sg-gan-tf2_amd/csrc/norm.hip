@@ -13,6 +13,9 @@
 // sum g*xhat) add a near-zero-mean field (the gradient that comes back through a SAME conv from another instance
 // norm), so the sum cancels to ~1e-3 of its terms and an f32 running sum over 64+ pixels is off by 1e-4 of the result --
 // visible against the float64 oracle (tools/diag_d_f32.py).  On the bf16 path the operands carry 8 bits: f32 is plenty.
+// pixels per loop trip in the streaming passes (= 16-byte loads in flight per thread and tensor): 4 forward; 2 backward, where
+// two tensors are read and 4 would cost occupancy (166 VGPRs: 3 waves/SIMD, measured 5-15 % slower than 2)
+#define IN_U (BWD ? 2 : 4)
 template <typename T> using InAcc = typename std::conditional<std::is_same<T, float>::value, double, float>::type;
 
 // Two networks of the same shape run in lockstep on a batch that stacks their activations (images 0..nsplit-1 belong to
@@ -73,25 +76,49 @@ __global__ __launch_bounds__(256) void in_partial_kernel(const char* x, const ch
                 gm[e] = gamma[c]; bt[e] = beta[c];
             }
         }
+        // IN_U pixels per trip: all their loads are issued before the first use (one 16-byte load in flight per thread left the
+        // pass latency bound), and the activation code is resolved once -- the element loop is then branch-free selects.
+        // The per-thread accumulation order (pixel order) is unchanged.
         if (prow < rows)
-            for (int64_t p = p0 + prow; p < p1; p += rows) {
-                size_t off = (((size_t)n * HW + p) * C + (size_t)cv * VEC) * sizeof(T);
-                float xv[VEC];
-                ET<T>::unpack(ld16(x + off), xv);
-                if (!BWD) {
+            act_dispatch(BWD ? act : SGG_ACT_NONE, [&](auto act_c) {
+                constexpr int ACT = decltype(act_c)::value;
+                auto accumulate = [&](const u32x4& xr, const float* gv) {
+                    float xv[VEC];
+                    ET<T>::unpack(xr, xv);
+                    if (!BWD) {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) { s1[e] += (AccT)xv[e]; s2[e] += (AccT)xv[e] * (AccT)xv[e]; }
-                } else {
-                    float gv[VEC];
-                    in_load_grad<T, TG>(dy, off / sizeof(T), gv);
+                        for (int e = 0; e < VEC; ++e) { s1[e] += (AccT)xv[e]; s2[e] += (AccT)xv[e] * (AccT)xv[e]; }
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        float xh = (xv[e] - mu[e]) * rs[e];
-                        float g = gv[e] * act_grad_from_pre(gm[e] * xh + bt[e], act, leak);
-                        s1[e] += (AccT)g; s2[e] += (AccT)g * (AccT)xh;
+                        for (int e = 0; e < VEC; ++e) {
+                            float xh = (xv[e] - mu[e]) * rs[e];
+                            float g = gv[e] * act_grad_c<ACT>(gm[e] * xh + bt[e], leak);
+                            s1[e] += (AccT)g; s2[e] += (AccT)g * (AccT)xh;
+                        }
                     }
+                };
+                const size_t base = ((size_t)n * HW * C + (size_t)cv * VEC) * sizeof(T), pstep = (size_t)C * sizeof(T);
+                int64_t p = p0 + prow;
+                for (; p + (IN_U - 1) * rows < p1; p += IN_U * rows) {
+                    u32x4 xr[IN_U];
+                    float gv[IN_U][BWD ? VEC : 1];
+#pragma unroll
+                    for (int u = 0; u < IN_U; ++u) xr[u] = ld16(x + base + (size_t)(p + u * rows) * pstep);
+                    if (BWD) {
+#pragma unroll
+                        for (int u = 0; u < IN_U; ++u) in_load_grad<T, TG>(dy, (base + (size_t)(p + u * rows) * pstep) / sizeof(T), gv[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < IN_U; ++u) accumulate(xr[u], gv[u]);
                 }
-            }
+                for (; p < p1; p += rows) {
+                    const size_t off = base + (size_t)p * pstep;
+                    float gv[BWD ? VEC : 1];
+                    const u32x4 xr = ld16(x + off);
+                    if (BWD) in_load_grad<T, TG>(dy, off / sizeof(T), gv);
+                    accumulate(xr, gv);
+                }
+            });
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][VEC + e] = s2[e]; }
         __syncthreads();
@@ -206,31 +233,62 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const char* x, const char
             A[e] = gm[e] * rs[e]; B[e] = bt[e] - mu[e] * A[e];
             if (BWD) { m1[e] = sums[((size_t)n * C + c) * 2]; m2[e] = sums[((size_t)n * C + c) * 2 + 1]; }
         }
-        for (int64_t p = p0 + prow; p < p1; p += rows) {
-            size_t off = (((size_t)n * HW + p) * C + (size_t)cv * VEC) * sizeof(T);
-            float xv[VEC], o[VEC];
-            ET<T>::unpack(ld16(x + off), xv);
-            if (!BWD) {
+        act_dispatch(act, [&](auto act_c) {
+            constexpr int ACT = decltype(act_c)::value;
+            auto sweep = [&](auto res_c) {
+                constexpr bool RES = decltype(res_c)::value;
+                auto one = [&](const u32x4& xr, const u32x4& rr, const float* gv, size_t off) {
+                    float xv[VEC], o[VEC];
+                    ET<T>::unpack(xr, xv);
+                    if (!BWD) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) o[e] = act_apply(xv[e] * A[e] + B[e], act, leak);
-                if (residual) {
-                    float rv[VEC];
-                    ET<T>::unpack(ld16(residual + off), rv);
+                        for (int e = 0; e < VEC; ++e) o[e] = act_apply_c<ACT>(xv[e] * A[e] + B[e], leak);
+                        if (RES) {
+                            float rv[VEC];
+                            ET<T>::unpack(rr, rv);
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) o[e] += rv[e];
+                            for (int e = 0; e < VEC; ++e) o[e] += rv[e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            float xh = (xv[e] - mu[e]) * rs[e];
+                            float g = gv[e] * act_grad_c<ACT>(gm[e] * xh + bt[e], leak);
+                            o[e] = A[e] * (g - m1[e] - xh * m2[e]);
+                        }
+                    }
+                    st16(out + off, ET<T>::pack(o));
+                };
+                const size_t base = ((size_t)n * HW * C + (size_t)cv * VEC) * sizeof(T), pstep = (size_t)C * sizeof(T);
+                int64_t p = p0 + prow;
+                for (; p + (IN_U - 1) * rows < p1; p += IN_U * rows) {      // IN_U pixels per trip, all loads first (see in_partial_kernel)
+                    u32x4 xr[IN_U], rr[IN_U];
+                    float gv[IN_U][BWD ? VEC : 1];
+#pragma unroll
+                    for (int u = 0; u < IN_U; ++u) {
+                        const size_t off = base + (size_t)(p + u * rows) * pstep;
+                        xr[u] = ld16(x + off);
+                        if (RES) rr[u] = ld16(residual + off);
+                    }
+                    if (BWD) {
+#pragma unroll
+                        for (int u = 0; u < IN_U; ++u) in_load_grad<T, TG>(dy, (base + (size_t)(p + u * rows) * pstep) / sizeof(T), gv[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < IN_U; ++u) one(xr[u], rr[u], gv[u], base + (size_t)(p + u * rows) * pstep);
                 }
-            } else {
-                float gv[VEC];
-                in_load_grad<T, TG>(dy, off / sizeof(T), gv);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    float xh = (xv[e] - mu[e]) * rs[e];
-                    float g = gv[e] * act_grad_from_pre(gm[e] * xh + bt[e], act, leak);
-                    o[e] = A[e] * (g - m1[e] - xh * m2[e]);
+                for (; p < p1; p += rows) {
+                    const size_t off = base + (size_t)p * pstep;
+                    float gv[BWD ? VEC : 1];
+                    const u32x4 xr = ld16(x + off);
+                    u32x4 rr = xr;
+                    if (RES) rr = ld16(residual + off);
+                    if (BWD) in_load_grad<T, TG>(dy, off / sizeof(T), gv);
+                    one(xr, rr, gv, off);
                 }
-            }
-            st16(out + off, ET<T>::pack(o));
-        }
+            };
+            if (!BWD && residual) sweep(std::true_type{}); else sweep(std::false_type{});
+        });
     }
 }
 
@@ -287,7 +345,7 @@ __global__ __launch_bounds__(256) void in_fused_small_kernel(const char* x, cons
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     const float xh = (xv[e] - mu[e]) * rs[e];
-                    const float g = gv[e] * act_grad_from_pre(gm[e] * xh + bt[e], act, leak);
+                    const float g = gv[e] * (act == SGG_ACT_RELU ? (gm[e] * xh + bt[e] > 0.f ? 1.f : 0.f) : act == SGG_ACT_LRELU ? (gm[e] * xh + bt[e] > 0.f ? 1.f : leak) : 1.f);
                     s1[e] += (AccT)g; s2[e] += (AccT)g * (AccT)xh;
                 }
             }
@@ -324,31 +382,34 @@ __global__ __launch_bounds__(256) void in_fused_small_kernel(const char* x, cons
         else { m1[e] = sh_a[cvl * VEC + e]; m2[e] = sh_b[cvl * VEC + e]; }
         A[e] = gm[e] * rs[e]; B[e] = bt[e] - mu[e] * A[e];
     }
-    for (int64_t p = prow; p < HW; p += ROWS) {
-        const size_t off = (((size_t)n * HW + p) * C + (size_t)cv * VEC) * sizeof(T);
-        float xv[VEC], o[VEC];
-        ET<T>::unpack(ld16(x + off), xv);
-        if (!BWD) {
+    act_dispatch(act, [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;
+        for (int64_t p = prow; p < HW; p += ROWS) {
+            const size_t off = (((size_t)n * HW + p) * C + (size_t)cv * VEC) * sizeof(T);
+            float xv[VEC], o[VEC];
+            ET<T>::unpack(ld16(x + off), xv);
+            if (!BWD) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) o[e] = act_apply(xv[e] * A[e] + B[e], act, leak);
-            if (residual) {
-                float rv[VEC];
-                ET<T>::unpack(ld16(residual + off), rv);
+                for (int e = 0; e < VEC; ++e) o[e] = act_apply_c<ACT>(xv[e] * A[e] + B[e], leak);
+                if (residual) {
+                    float rv[VEC];
+                    ET<T>::unpack(ld16(residual + off), rv);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) o[e] += rv[e];
+                    for (int e = 0; e < VEC; ++e) o[e] += rv[e];
+                }
+            } else {
+                float gv[VEC];
+                ET<T>::unpack(ld16(dy + off), gv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float xh = (xv[e] - mu[e]) * rs[e];
+                    const float g = gv[e] * act_grad_c<ACT>(gm[e] * xh + bt[e], leak);
+                    o[e] = A[e] * (g - m1[e] - xh * m2[e]);
+                }
             }
-        } else {
-            float gv[VEC];
-            ET<T>::unpack(ld16(dy + off), gv);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float xh = (xv[e] - mu[e]) * rs[e];
-                const float g = gv[e] * act_grad_from_pre(gm[e] * xh + bt[e], act, leak);
-                o[e] = A[e] * (g - m1[e] - xh * m2[e]);
-            }
+            st16(out + off, ET<T>::pack(o));
         }
-        st16(out + off, ET<T>::pack(o));
-    }
+    });
 }
 
 __global__ void in_param_grad_kernel(InParamGrad g, int C, InSplit sp) { in_param_grad(g, C, sp); }
@@ -394,7 +455,7 @@ static int instnorm_fwd_impl(const void* x, const float* gamma, const float* bet
     if (dtype == SGG_BF16) {
         hipLaunchKernelGGL((in_partial_kernel<bf16, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak, sp);
         hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, stats, HW, C, chunks, eps);
-        hipLaunchKernelGGL((in_apply_kernel<bf16, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{}, sp);
+        sgg_launch_timed(in_apply_kernel<bf16, false>, ga, dim3(256), 0u, s, (const char*)x, (const char*)nullptr, (const char*)residual, gamma, beta, (const float*)stats, (const float*)nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{}, sp);
     } else if (dtype == SGG_F32) {
         hipLaunchKernelGGL((in_partial_kernel<float, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak, sp);
         hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, stats, HW, C, chunks, eps);
@@ -413,7 +474,7 @@ static int instnorm_fwd_partial_impl(const void* x, const float* gamma, const fl
     int rpb = in_rows_per_block(N, HW, C, 0);
     dim3 ga((unsigned)((HW + rpb - 1) / rpb), N);
     hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, stats, HW, C, chunks, eps);
-    if (dtype == SGG_BF16) hipLaunchKernelGGL((in_apply_kernel<bf16, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{}, sp);
+    if (dtype == SGG_BF16) sgg_launch_timed(in_apply_kernel<bf16, false>, ga, dim3(256), 0u, s, (const char*)x, (const char*)nullptr, (const char*)residual, gamma, beta, (const float*)stats, (const float*)nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{}, sp);
     else hipLaunchKernelGGL((in_apply_kernel<float, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{}, sp);
     return sgg_check_launch();
 }

@@ -342,7 +342,7 @@ def instnorm_fwd(x, gamma, beta, residual=None, eps=1e-3, act=A.ACT_NONE, leak=0
     y = torch.empty_like(x)
     stats = torch.empty((N, Cp, 2), dtype=torch.float32, device=x.device)
     ws = workspace(int(A.lib().sgg_instnorm_workspace(N, H * W, Cp)), x.device)
-    pr = _prof("instnorm_fwd", tuple(x.shape))
+    pr = _prof("instnorm_fwd", (tuple(x.shape), residual is not None))
     if pr: pr.start()
     A.check(A.lib().sgg_instnorm_fwd(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(stats), N, H * W, Cp, eps, act, leak,
                                      dt(x), _p(ws), ws.numel(), _s()), "instnorm_fwd")
@@ -356,7 +356,7 @@ def instnorm_fwd_partial(x, partial, gamma, beta, residual=None, eps=1e-3, act=A
     assert gamma.numel() == Cp and beta.numel() == Cp and partial.shape[0] == N and partial.shape[2] == Cp
     y = torch.empty_like(x)
     stats = torch.empty((N, Cp, 2), dtype=torch.float32, device=x.device)
-    pr = _prof("instnorm_fwd_partial", tuple(x.shape))
+    pr = _prof("instnorm_fwd_partial", (tuple(x.shape), residual is not None))
     if pr: pr.start()
     A.check(A.lib().sgg_instnorm_fwd_partial(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(stats), _p(partial), partial.shape[1],
                                              N, H * W, Cp, eps, act, leak, dt(x), _s()), "instnorm_fwd_partial")
@@ -396,8 +396,11 @@ def instnorm_fwd_pair(x, gamma, beta, gamma2, beta2, nsplit, residual=None, eps=
     y = torch.empty_like(x)
     stats = torch.empty((N, Cp, 2), dtype=torch.float32, device=x.device)
     ws = workspace(int(A.lib().sgg_instnorm_workspace(N, H * W, Cp)), x.device)
+    pr = _prof("instnorm_fwd_pair", (tuple(x.shape), residual is not None))
+    if pr: pr.start()
     A.check(A.lib().sgg_instnorm_fwd_pair(_p(x), _p(gamma), _p(beta), _p(gamma2), _p(beta2), nsplit, _p(residual), _p(y), _p(stats), N, H * W, Cp,
                                           eps, act, leak, dt(x), _p(ws), ws.numel(), _s()), "instnorm_fwd_pair")
+    if pr: pr.stop()
     return y, stats
 
 
@@ -406,8 +409,11 @@ def instnorm_fwd_partial_pair(x, partial, gamma, beta, gamma2, beta2, nsplit, re
     assert gamma.numel() == Cp and gamma2.numel() == Cp and partial.shape[0] == N and partial.shape[2] == Cp and 0 < nsplit < N
     y = torch.empty_like(x)
     stats = torch.empty((N, Cp, 2), dtype=torch.float32, device=x.device)
+    pr = _prof("instnorm_fwd_partial_pair", (tuple(x.shape), residual is not None))
+    if pr: pr.start()
     A.check(A.lib().sgg_instnorm_fwd_partial_pair(_p(x), _p(gamma), _p(beta), _p(gamma2), _p(beta2), nsplit, _p(residual), _p(y), _p(stats),
                                                   _p(partial), partial.shape[1], N, H * W, Cp, eps, act, leak, dt(x), _s()), "instnorm_fwd_partial_pair")
+    if pr: pr.stop()
     return y, stats
 
 

@@ -18,12 +18,16 @@ sys.path.insert(0, os.path.join(ROOT, "sg-gan-tf2_amd"))
 
 # mangled-name fragments of the kernels that must not spill (production tile configurations)
 MUST_NOT_SPILL = [
-    "conv3x3_halo_gemm_kernelILi0ELb0ELi0E",                   # 3x3 forward, halo resident
-    "conv3x3_halo_gemm_kernelILi0ELb0ELi1E",                   # ... with the norm-statistics epilogue (the roofline kernel)
-    "conv3x3_halo_gemm_kernelILi1ELb0ELi0E",                   # 3x3 data gradient, zero padding
-    "conv3x3_halo_gemm_kernelILi1ELb1ELi0E",                   # 3x3 data gradient, REFLECT fold
-    # (the opt-in <DGRAD, *, STATS=2> variants -- norm-backward sums in the epilogue, off by default, measured slower -- are
-    #  allowed their 2 spilled VGPRs)
+    # conv3x3_halo_gemm_kernel<MODE, FOLD, STATS, PAIR>: every instantiation the library dispatches
+    "conv3x3_halo_gemm_kernelILi0ELb0ELi0ELb0E",               # 3x3 forward, halo resident
+    "conv3x3_halo_gemm_kernelILi0ELb0ELi1ELb0E",               # ... with the norm-statistics epilogue
+    "conv3x3_halo_gemm_kernelILi0ELb0ELi0ELb1E",               # ... on a stacked pair of networks
+    "conv3x3_halo_gemm_kernelILi0ELb0ELi1ELb1E",               # ... both (the roofline kernel of the cycle step)
+    "conv3x3_halo_gemm_kernelILi1ELb0ELi0ELb0E",               # 3x3 data gradient, zero padding
+    "conv3x3_halo_gemm_kernelILi1ELb1ELi0ELb0E",               # 3x3 data gradient, REFLECT fold
+    "conv3x3_halo_gemm_kernelILi1ELb0ELi0ELb1E", "conv3x3_halo_gemm_kernelILi1ELb1ELi0ELb1E",   # ... paired
+    "conv3x3_halo_gemm_kernelILi1ELb0ELi2ELb0E",               # ... with the norm-backward sums (opt-in, off by default)
+    # (<DGRAD, FOLD, STATS=2>, the same for REFLECT padding -- opt-in, measured slower -- is allowed its 2 spilled VGPRs)
     "conv3x3_wgrad_halo_kernel",                               # 3x3 weight gradient, all taps per block
     "conv3x3_wgrad_halo_s2_kernel",                            # the same for stride 2
     "deconv_s2_halo_kernel",                                   # stride-2 data gradient / Conv2DTranspose forward

@@ -20,7 +20,7 @@ def timeit(f, iters=30):
     return s.elapsed_time(e) / iters * 1e3
 
 
-SHAPES = ((8, 64, 128, 256), (8, 128, 256, 128), (8, 256, 512, 64), (8, 32, 64, 256), (8, 5, 13, 512))
+SHAPES = ((8, 64, 128, 256), (16, 64, 128, 256), (8, 128, 256, 128), (8, 256, 512, 64), (8, 32, 64, 256), (8, 5, 13, 512))
 if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "res":
     SHAPES = SHAPES[:1]                       # the residual-block tensor only (PMC passes: tools/pmc_in.sh)
 DIR = sys.argv[sys.argv.index("--dir") + 1] if "--dir" in sys.argv else "both"

@@ -2,6 +2,7 @@
 # Round-2 measurement set (run ON the GPU box, one call): bash tools/r2_profile.sh
 #   gpurun_out/r2final/: bench lines (default, eager, reference mode, configs 1/2/5 shapes, torchrun N=1, mixed), rocprofv3
 #   kernel stats of the default bench command, the per-layer table, PMC passes (HBM traffic, LDS conflicts / MFMA busy, norms)
+set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r2final
 mkdir -p $O

@@ -1090,12 +1090,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         }
         return;
     }
-    // STATS 2: one 16-channel group at a time, to keep that group's norm constants in registers.  The norm's input tile
-    // (2 rows x 128 pixels x 256 channels = 128 KB) is first DMA'd into LDS -- the halo and the weight stages are free now --
-    // with coalesced 16-byte pieces, and each lane then picks its 8-byte (pixel, 4 channels) groups out of LDS.  (Reading
-    // them straight from global memory, 32 scattered 8-byte loads per lane, cost +27 us per launch.)  512-byte pixel rows,
-    // 16-byte chunk c of pixel p at position c ^ (p & 31): the 16 pixels a ds_read_b64 touches hit 16 different chunks.
-    const float* const bias_n = a.bias;                                       // (STATS 2 has no paired form)
+    // STATS 2 (data gradient; no bias, no activation -- run_gemm checks).  The norm's input tile (2 rows x 128 pixels x 256
+    // channels = 128 KB) is first DMA'd into LDS -- the halo and the weight stages are free now -- with coalesced 16-byte
+    // pieces, and each lane then picks its 8-byte (pixel, 4 channels) groups out of LDS: 512-byte pixel rows, 16-byte chunk c
+    // of pixel p at position c ^ (p & 31), so the 16 pixels a ds_read_b64 touches hit 16 different chunks.
+    // Per lane and channel only two constants stay in registers, the norm's affine form A = gamma*rstd, B = beta - mean*A
+    // (the sign of A*x + B is the activation mask, as in in_apply_kernel); the sums are (sum g, sum g*x) and the chunk's
+    // second sum is recovered at the end as rstd * (sum g*x - mean * sum g).  Pixel-major store order as above; two pixels'
+    // addend loads and LDS reads are in flight at a time.
     if constexpr (STATS == 2) {
         for (int id = wave; id < 128; id += 8) {         // 128 wave-instructions of 2 pixels x 512 B
             const int p = id * 2 + (lane >> 5), pos = lane & 31;
@@ -1105,66 +1107,92 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(lH + id * 1024), 16, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
+        float cA[NI][4], cB[NI][4], s1[NI][4], s2[NI][4];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int dc = n0 + wn * WN + i * 16 + fq * 4;
-        if (dc >= DC) continue;
-        float bv[4], s1[4], s2[4], mu[4], rs[4], gm[4], bt[4];
+        for (int i = 0; i < NI; ++i) {
+            const int dc = n0 + wn * WN + i * 16 + fq * 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            bv[e] = bias_n ? bias_n[dc + e] : 0.f;
-            s1[e] = s2[e] = 0.f;
-            if (STATS == 2) {
-                mu[e] = a.nstats[((size_t)img * DC + dc + e) * 2]; rs[e] = a.nstats[((size_t)img * DC + dc + e) * 2 + 1];
-                gm[e] = a.ngamma[dc + e]; bt[e] = a.nbeta[dc + e];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < MI; ++j) {
-            const size_t dpix = prow + j * 16 + frow;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[i][j][e] + bv[e], a.act, a.leak);
-            if (a.addend) {
-                const bf16* ad = reinterpret_cast<const bf16*>(a.addend) + dpix * DC + dc;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)ad[e];
-            }
-            bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.dst) + dpix * DC + dc) = pk;
-            if (STATS == 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float vr = (float)pk[e]; s1[e] += vr; s2[e] += vr * vr; }
-            }
-            if (STATS == 2) {
-                const int pl = wm * 128 + j * 16 + frow, cl = wn * WN + i * 16 + fq * 4;      // tile pixel, tile channel
-                const bf16x4 xq = *reinterpret_cast<const bf16x4*>(smem + (size_t)pl * 512 + (((cl >> 3) ^ (pl & 31)) << 4) + (cl & 7) * 2);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float xh = ((float)xq[e] - mu[e]) * rs[e];
-                    const float g = (float)pk[e] * act_grad_from_pre(gm[e] * xh + bt[e], a.nact, a.nleak);
-                    s1[e] += g; s2[e] += g * xh;
+            for (int e = 0; e < 4; ++e) {
+                cA[i][e] = cB[i][e] = s1[i][e] = s2[i][e] = 0.f;
+                if (dc < DC) {
+                    const float mu = a.nstats[((size_t)img * DC + dc + e) * 2], rs = a.nstats[((size_t)img * DC + dc + e) * 2 + 1];
+                    cA[i][e] = a.ngamma[dc + e] * rs;
+                    cB[i][e] = a.nbeta[dc + e] - mu * cA[i][e];
                 }
             }
         }
-        if (STATS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const size_t e0 = (prow + frow) * DC + n0 + wn * WN + fq * 4;
+        const size_t ej = (size_t)16 * DC;
+        act_dispatch(a.nact, [&](auto nact_c) {
+            constexpr int NACT = decltype(nact_c)::value;
+            auto run = [&](auto has_add) {
+                constexpr bool ADD = decltype(has_add)::value;
+#pragma unroll
+                for (int j0 = 0; j0 < MI; j0 += 2) {
+                    bf16x4 adv[2][NI], xq[2][NI];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) {
+                            const int j = j0 + jj, dc = n0 + wn * WN + i * 16 + fq * 4;
+                            const int pl = wm * 128 + j * 16 + frow, cl = wn * WN + i * 16 + fq * 4;      // tile pixel, tile channel
+                            xq[jj][i] = *reinterpret_cast<const bf16x4*>(smem + (size_t)pl * 512 + (((cl >> 3) ^ (pl & 31)) << 4) + (cl & 7) * 2);
+                            if constexpr (ADD) {
+                                adv[jj][i] = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+                                if (dc < DC) adv[jj][i] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(a.addend) + e0 + j * ej + i * 16);
+                            }
+                        }
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) {
+                            const int j = j0 + jj, dc = n0 + wn * WN + i * 16 + fq * 4;
+                            if (dc >= DC) continue;
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
+                            if constexpr (ADD) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += (float)adv[jj][i][e];
+                            }
+                            bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.dst) + e0 + j * ej + i * 16) = pk;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float xv = (float)xq[jj][i][e];
+                                const float g = (float)pk[e] * act_grad_c<NACT>(cA[i][e] * xv + cB[i][e], a.nleak);
+                                s1[i][e] += g; s2[i][e] += g * xv;
+                            }
+                        }
+                }
+            };
+            if (a.addend) run(std::true_type{}); else run(std::false_type{});
+        });
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
 #pragma unroll
                 for (int off = 1; off < 16; off <<= 1) {
-                    s1[e] += __shfl_xor(s1[e], off);
-                    s2[e] += __shfl_xor(s2[e], off);
+                    s1[i][e] += __shfl_xor(s1[i][e], off);
+                    s2[i][e] += __shfl_xor(s2[i][e], off);
                 }
             }
-            if (frow == 0) {
-                const int chunks = tilesH * tilesW * 2;
-                const int chunk = (th * tilesW + tw) * 2 + wm;
+        if (frow == 0) {
+            const int chunks = tilesH * tilesW * 2;
+            const int chunk = (th * tilesW + tw) * 2 + wm;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int dc = n0 + wn * WN + i * 16 + fq * 4;
+                if (dc >= DC) continue;
                 float* o = a.stats + (((size_t)img * chunks + chunk) * DC + dc) * 2;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { o[2 * e] = s1[e]; o[2 * e + 1] = s2[e]; }
+                for (int e = 0; e < 4; ++e) {
+                    const float mu = a.nstats[((size_t)img * DC + dc + e) * 2], rs = a.nstats[((size_t)img * DC + dc + e) * 2 + 1];
+                    o[2 * e] = s1[i][e]; o[2 * e + 1] = rs * (s2[i][e] - mu * s1[i][e]);
+                }
             }
         }
     }
@@ -3039,8 +3067,11 @@ static int launch_gemm(const ConvArgs& a, hipStream_t s) {
         if (halo3_ok(a, MODE, true)) {
             if constexpr (MODE == MODE_DGRAD) {
                 const bool pair = a.wmat2 != nullptr;
-                if (pair && a.stats) return SGG_EUNSUPPORTED;
-                if (a.reflect) return a.stats ? launch_halo3<MODE_DGRAD, true, 2>(a, s) : pair ? launch_halo3<MODE_DGRAD, true, 0, true>(a, s) : launch_halo3<MODE_DGRAD, true>(a, s);
+                if (a.stats && (pair || a.dst_f32 || a.addend_f32)) return SGG_EUNSUPPORTED;   // (the norm-backward sums have no paired / mixed form)
+                if (a.reflect) {
+                    if (a.stats) return launch_halo3<MODE_DGRAD, true, 2>(a, s);
+                    return pair ? launch_halo3<MODE_DGRAD, true, 0, true>(a, s) : launch_halo3<MODE_DGRAD, true>(a, s);
+                }
                 if (a.stats) return launch_halo3<MODE_DGRAD, false, 2>(a, s);
                 if (pair) return launch_halo3<MODE_DGRAD, false, 0, true>(a, s);
             }
@@ -3733,11 +3764,11 @@ static int conv2d_bwd_data_impl(const sgg_conv_desc* d, const void* dy, const vo
     ConvArgs a = make_args(d, dy, w, nullptr, dx, SGG_ACT_NONE, 0.f);
     a.addend = (const char*)addend;
     if (nb && nb->w2) { a.wmat2 = (const char*)nb->w2; a.nsplit = nb->nsplit; }
-    if (nb && (nb->mixed || nb->w2)) { a.dst_f32 = nb->mixed & 1; a.addend_f32 = (nb->mixed >> 1) & 1; nb = nullptr; }
-    if (nb) {
+    if (nb && nb->mixed) { a.dst_f32 = nb->mixed & 1; a.addend_f32 = (nb->mixed >> 1) & 1; }
+    if (nb && nb->partial) {
         a.stats = nb->partial; a.nx = (const char*)nb->nx; a.nstats = nb->nstats; a.ngamma = nb->ngamma; a.nbeta = nb->nbeta;
         a.nact = nb->nact; a.nleak = nb->nleak;
-    }
+    } else nb = nullptr;                                 // from here on `nb` means: norm-backward sums wanted
     if (!addend && halo_narrow_in_ok(d, d->K, d->C)) {  // data-gradient of a narrow-OUTPUT conv (the head): dy has 8 channels
         int rc0 = d->dtype == SGG_BF16 ? launch_halo_narrow_in<bf16>(d, a, 1, (hipStream_t)stream) : launch_halo_narrow_in<float>(d, a, 1, (hipStream_t)stream);
         if (rc0 || !a.reflect) return rc0;

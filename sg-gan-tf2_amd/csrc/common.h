@@ -127,6 +127,20 @@ __device__ inline void dma16_to_lds(const void* gsrc, __attribute__((address_spa
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m) : "memory", "m0");
 }
 
+__device__ inline void dma4_to_lds(const void* gsrc, __attribute__((address_space(3))) void* lds_wave_base) {   // 4 bytes per lane at m0 + 4 * lane
+    const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(m) : "memory", "m0");
+}
+// ... and the waits as BUILTINS (s_waitcnt simm16, gfx9 encoding: vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14): unlike an
+// asm string they are seen by the waitcnt pass, which then knows what is outstanding and counts its own waits from there.
+template <int N> __device__ inline void sgg_wait_vm() {                 // until at most N vector-memory operations are outstanding
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70);
+    asm volatile("" ::: "memory");
+}
+#define SGG_WAIT_VM0() sgg_wait_vm<0>()
+#define SGG_WAIT_LGKM0() do { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); } while (0)
+
 static inline int sgg_check_launch() { return hipGetLastError() == hipSuccess ? SGG_OK : SGG_ELAUNCH; }
 
 // Kernels that need more than 64 KB of dynamic LDS must have the attribute raised once PER DEVICE (a process may drive

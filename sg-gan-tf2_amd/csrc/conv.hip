@@ -560,14 +560,12 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < QA; ++i) {
             const char* src = qbase[i] + (((qok >> i) & 1u) ? coff : 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sQ + (wave * RPW + RPP * i) * BKB), 16, 0, 0);
+            dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sQ + (wave * RPW + RPP * i) * BKB));
         }
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const char* src = pbase[i] + (((pok >> i) & 1u) ? coff : 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sP + (wave * RPW + RPP * i) * BKB), 16, 0, 0);
+            dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sP + (wave * RPW + RPP * i) * BKB));
         }
         t_cc += CPR;
         while (t_cc >= cpv) { t_cc -= cpv; tapchg = true; if (++t_si == ns) { t_si = 0; ++t_ri; } }
@@ -585,8 +583,8 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
     // NS-stage ring: NS-1 tiles are in flight by DMA while one is multiplied; counted vmcnt leaves NS-2 of them
     // outstanding across the (raw) barrier -- a __syncthreads() there would drain the whole queue.
     auto wait_tiles = [&](bool steady) {
-        if (steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (steady) sgg_wait_vm<(NS - 2) * LPT>();
+        else SGG_WAIT_VM0();
     };
     for (int t = 0; t < NS - 1; ++t)
         if (t < ktiles) stage_tile(t);
@@ -640,7 +638,7 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
             }
         }
         wait_tiles(refill);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SGG_WAIT_LGKM0();
         if (SGG_ABLATE_OF(a) < 3) __builtin_amdgcn_s_barrier();
     }
 
@@ -726,18 +724,6 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
 #ifndef H3_GJ
 #define H3_GJ 4                                        // pixel fragments per MFMA group of the main loop (x 4 weight fragments = 16 MFMAs)
 #endif
-#ifndef H3_ASM_DMA
-#define H3_ASM_DMA 1                                   // LDS-DMA through dma16_to_lds (common.h) instead of the builtin
-#endif
-#if H3_ASM_DMA
-#define H3_DMA(src, ldsp) dma16_to_lds(src, (__attribute__((address_space(3))) void*)(ldsp))
-#else
-#define H3_DMA(src, ldsp) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(ldsp), 16, 0, 0)
-#endif
-// waits as BUILTINS (s_waitcnt simm16, gfx9 encoding: vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14): unlike an asm
-// string they are seen by hipcc's waitcnt pass, which then knows that nothing is outstanding and counts its own waits from there
-#define H3_WAIT_VM0() do { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); } while (0)
-#define H3_WAIT_LGKM0() do { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); } while (0)
 #define H3_PITCH 136                                   // halo row pitch in pixels (130 used; multiple of 8 = one DMA)
 #define H3_HALO_BYTES (4 * H3_PITCH * 128)
 #define H3_PATCH_ROWS 40                               // 2 tile rows x 2 sides x 9 taps = 36, rounded to whole DMAs
@@ -824,7 +810,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             else ok = ok && (unsigned)wi < (unsigned)a.W;
             const int key = (((k * H3_PITCH + hp) >> 1) & 7);
             const char* src = ok ? rowp + (size_t)wi * SC * 2 + ((hpos ^ key) << 4) : zero;
-            H3_DMA(src, lH + (k * H3_PITCH + q * 8) * 128);
+            dma16_to_lds(src, (__attribute__((address_space(3))) void*)(lH + (k * H3_PITCH + q * 8) * 128));
         }
     };
 
@@ -843,7 +829,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             // a.fold first part: [N][H][2 sides][9 weight taps][SC]; halo tap t pairs with weight tap 8 - t
             const char* src = ok ? a.fold + (((((size_t)img * a.H + h0 + tr) * 2 + side) * 9 + (8 - tap_h)) * SC + chunk * 64) * 2 + ((hpos ^ key) << 4)
                                  : zero;
-            H3_DMA(src, lPatch + ((chunk & 1) * H3_PATCH_ROWS + pw * 8) * 128);
+            dma16_to_lds(src, (__attribute__((address_space(3))) void*)(lPatch + ((chunk & 1) * H3_PATCH_ROWS + pw * 8) * 128));
         }
     };
 
@@ -862,7 +848,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             if (d >= 32) break;
             const bool ok = n0 + d * 8 + wl < DC;
             const char* src = ok ? wbase + d * wstride8 + off + (wsw ^ ((d & 1) << 6)) : zero;
-            H3_DMA(src, sQ + d * 8 * 128);
+            dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sQ + d * 8 * 128));
         }
     };
 
@@ -880,7 +866,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     for (int k = 0; k < 4; ++k) load_halo_row(k, 0, wave, 8);
     load_patch(0, wave, 8);
     load_w(0, 0, MODE == MODE_FWD ? 0 : 8, wave, 8);
-    H3_WAIT_VM0();
+    SGG_WAIT_VM0();
     __builtin_amdgcn_s_barrier();
 
     const int ntiles = abl >= 5 ? 0 : nchunk * 9;
@@ -973,9 +959,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             }
         }
         H3_STAMP(2);
-        H3_WAIT_VM0();
+        SGG_WAIT_VM0();
         H3_STAMP(3);
-        H3_WAIT_LGKM0();
+        SGG_WAIT_LGKM0();
         H3_STAMP(4);
         if (abl < 3) __builtin_amdgcn_s_barrier();
         H3_STAMP(5);
@@ -1122,7 +1108,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             const int chunk = pos ^ (p & 31);
             const bool ok = n0 + chunk * 8 < DC;
             const char* src = ok ? a.nx + ((((size_t)img * a.H + h0 + (p >> 7)) * a.W + w0 + (p & 127)) * DC + n0 + chunk * 8) * 2 : zero;
-            H3_DMA(src, lH + id * 1024);
+            dma16_to_lds(src, (__attribute__((address_space(3))) void*)(lH + id * 1024));
         }
         float cA[NI][4], cB[NI][4], s1[NI][4], s2[NI][4];
 #pragma unroll
@@ -1138,7 +1124,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
                 }
             }
         }
-        H3_WAIT_VM0();
+        SGG_WAIT_VM0();
         __builtin_amdgcn_s_barrier();
         const size_t e0 = (prow + frow) * DC + n0 + wn * WN + fq * 4;
         const size_t ej = (size_t)16 * DC;
@@ -1282,8 +1268,7 @@ __global__ __launch_bounds__(512) void deconv_s2_halo_kernel(ConvArgs a, int tot
             const bool ok = hp < S2_TJ + 2 && (unsigned)hi < (unsigned)a.Ho && (unsigned)wi < (unsigned)a.Wo;
             const int key = ((k * S2_PITCH + hp) >> 1) & 7;
             const char* src = ok ? a.src + ((((size_t)T.img * a.Ho + hi) * a.Wo + wi) * SC + chunk * 64) * 2 + ((hpos ^ key) << 4) : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dstb + (k * S2_PITCH + cg * 8) * 128), 16, 0, 0);
+            dma16_to_lds(src, (__attribute__((address_space(3))) void*)(dstb + (k * S2_PITCH + cg * 8) * 128));
         }
     };
     // weights of kernel row r, chunk: 3 taps x 64 rows x 128 B = 24 DMAs of 8 rows; wave w issues 3w..3w+2
@@ -1295,8 +1280,7 @@ __global__ __launch_bounds__(512) void deconv_s2_halo_kernel(ConvArgs a, int tot
             const int sx = q >> 3, row = (q & 7) * 8 + hsub;
             const int key = (((sx * 64 + row) >> 1) & 7);
             const char* src = a.wmat + ((size_t)(T.n0 + row) * wrow + (size_t)(r * 3 + sx) * SC + chunk * 64) * 2 + ((hpos ^ key) << 4);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dstb + q * 1024), 16, 0, 0);
+            dma16_to_lds(src, (__attribute__((address_space(3))) void*)(dstb + q * 1024));
         }
     };
 
@@ -1305,7 +1289,7 @@ __global__ __launch_bounds__(512) void deconv_s2_halo_kernel(ConvArgs a, int tot
     Tile cur = decode(t_beg);
     load_halo(0, cur, 0);
     load_w(0, cur, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SGG_WAIT_VM0();
     __builtin_amdgcn_s_barrier();
 
     const int nqc = (t_end - t_beg) * nchunk;          // (tile, chunk) pairs of this block
@@ -1360,8 +1344,8 @@ __global__ __launch_bounds__(512) void deconv_s2_halo_kernel(ConvArgs a, int tot
                             acc[cls][j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[kk][i]),
                                                                                       __builtin_bit_cast(bf16x8, fp[kk][j]), acc[cls][j][i], 0, 0, 0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SGG_WAIT_VM0();
+            SGG_WAIT_LGKM0();
             __builtin_amdgcn_s_barrier();
         }
         if (last_chunk) {
@@ -1544,8 +1528,7 @@ __global__ __launch_bounds__(512) void conv_halo_fwd_kernel(ConvArgs a, int flip
                 if (ok) src = a.src + ((((size_t)n * a.H + yi) * a.W + xi) * a.C + cc * CCH) * ES + lcc * 16;
             }
             if (base + wave * 8 < HP + 8)                // wave-uniform: skip instructions wholly past the halo
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(sH + (base + wave * 8) * 128), 16, 0, 0);
+                dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sH + (base + wave * 8) * 128));
         }
     };
     auto stage_weights = [&](int buf, int r, int cc) {   // taps (r, 0..S-1): rows = s*16 + cout
@@ -1558,8 +1541,7 @@ __global__ __launch_bounds__(512) void conv_halo_fwd_kernel(ConvArgs a, int flip
                 if (k < a.K) src = a.wmat + ((size_t)k * wrow + (size_t)tap * a.C + cc * CCH) * ES + lcc * 16;
             }
             if (base + wave * 8 < a.S * 16)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(sW + buf * WBUF + (base + wave * 8) * 128), 16, 0, 0);
+                dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sW + buf * WBUF + (base + wave * 8) * 128));
         }
     };
 
@@ -1573,7 +1555,7 @@ __global__ __launch_bounds__(512) void conv_halo_fwd_kernel(ConvArgs a, int flip
         __syncthreads();                                 // previous pass has finished reading the halo
         stage_halo(cc);
         stage_weights(0, 0, cc);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SGG_WAIT_VM0();
         __syncthreads();
         for (int r = 0; r < a.R; ++r) {
             const int cur = r & 1;
@@ -1598,7 +1580,7 @@ __global__ __launch_bounds__(512) void conv_halo_fwd_kernel(ConvArgs a, int flip
                     }
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SGG_WAIT_VM0();
             __syncthreads();
         }
     }
@@ -1703,8 +1685,7 @@ __global__ __launch_bounds__(512) void conv7_narrow_out_kernel(N7Args a) {
             const int hp = hy * N7_PITCH + hx;
             const int key = (hp >> 1) & 7;
             const char* src = ok ? a.src + ((((size_t)n * a.H + yi) * a.W + xi) * 64) * 2 + ((hpos ^ key) << 4) : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lH + (hy * N7_PITCH + (id - hy * 9) * 8) * 128), 16, 0, 0);
+            dma16_to_lds(src, (__attribute__((address_space(3))) void*)(lH + (hy * N7_PITCH + (id - hy * 9) * 8) * 128));
         }
     }
     f32x4 acc[5][2];
@@ -1712,7 +1693,7 @@ __global__ __launch_bounds__(512) void conv7_narrow_out_kernel(N7Args a) {
     for (int qf = 0; qf < 5; ++qf)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[qf][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SGG_WAIT_VM0();
     __syncthreads();
 
     // ---- D[q][(co,s)] for this wave's output row: A operand = halo pixels (lane: pixel frow, chunk fq), B = weights
@@ -1751,7 +1732,7 @@ __global__ __launch_bounds__(512) void conv7_narrow_out_kernel(N7Args a) {
                 }
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SGG_WAIT_LGKM0();
     __builtin_amdgcn_wave_barrier();
     const int y = y0 + wave, x = x0 + lane;
     float o[3];
@@ -1845,7 +1826,7 @@ struct W7Args {
     int ablate;          // lab build only (SGG_ABLATE): 1 no fragment reads / MFMAs, 2 no Bs build, 3 no A-row DMA in the loop
 };
 
-template <int N> __device__ inline void w7_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ inline void w7_wait_vm() { sgg_wait_vm<N>(); }
 
 template <int RS, int PD>
 __global__ __launch_bounds__(512) void wgrad7_kernel(W7Args a) {
@@ -1879,8 +1860,7 @@ __global__ __launch_bounds__(512) void wgrad7_kernel(W7Args a) {
             const bool ok = (unsigned)yi < (unsigned)a.HA && (unsigned)xi < (unsigned)a.WA;
             const int key = ((q >> 1) & 1) | (((q >> 3) & 1) << 1);           // keyed on pixel bits 1 and 3: the transposed reads are conflict-free
             const char* src = ok ? a.A + ((((size_t)n * a.HA + yi) * a.WA + xi) * 64) * 2 + ((hpos ^ (key << 1)) << 4) : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds + (k % Cfg::RING) * W7_AROW + i * 1024), 16, 0, 0);
+            dma16_to_lds(src, (__attribute__((address_space(3))) void*)(lds + (k % Cfg::RING) * W7_AROW + i * 1024));
         }
     };
     // ---- B rows of a step (wave 7): raw row DMA, then the im2col Bs[q][(j,s)] = B[q - s][j]
@@ -1891,8 +1871,7 @@ __global__ __launch_bounds__(512) void wgrad7_kernel(W7Args a) {
             const char* src = ok ? a.B + (((size_t)n * a.HB + py) * a.WB + px) * 16 : zero;
 #pragma unroll
             for (int part = 0; part < 2; ++part)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + part * 4),
-                                                 (__attribute__((address_space(3))) void*)(lds + Cfg::OFF_BRAW + ((step & 3) * RS + i) * 512 + part * 256), 4, 0, 0);
+                dma4_to_lds(src + part * 4, (__attribute__((address_space(3))) void*)(lds + Cfg::OFF_BRAW + ((step & 3) * RS + i) * 512 + part * 256));
         }
     };
     auto build_bs = [&](int step) {
@@ -1946,13 +1925,13 @@ __global__ __launch_bounds__(512) void wgrad7_kernel(W7Args a) {
     // prologue (all 8 waves issue, everything is drained): A rows of steps 0 .. PD-1, raw B of steps 0 and 1, Bs of step 0
     if (wave == 7) load_b_raw(0);
     load_a_rows(0, RS + 6 + (PD - 1) * RS, wave, 8);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SGG_WAIT_VM0();
     if (wave == 7) {
         build_bs(0);
         load_b_raw(1);
         load_b_raw(2);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SGG_WAIT_LGKM0();
     __syncthreads();
 
     // Transposed fragment reads: lane 4qq+pp of 16-lane group g supplies row (pixel) 8g+qq [+4 for the upper half], columns
@@ -2017,10 +1996,10 @@ __global__ __launch_bounds__(512) void wgrad7_kernel(W7Args a) {
             if (SGG_ABLATE_OF(a) != 2) build_bs(t + 1);
             load_b_raw(t + 3);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SGG_WAIT_LGKM0();
         __syncthreads();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing may still be writing LDS when the block retires
+    SGG_WAIT_VM0();     // nothing may still be writing LDS when the block retires
 
     // D_r[row = it*16 + 4g + e -> channel c][col = jt*16 + u -> (j,s)]
     if (wave < 7) {
@@ -2243,15 +2222,14 @@ __global__ __launch_bounds__(512) void conv_halo_wgrad_kernel(WgradArgs a, int n
                     if (ok) src = a.x + ((((size_t)n * a.H + yi) * a.W + xi) * a.C + cc * CCH) * ES + lcc * 16;
                 }
                 if (base + wave * 8 < HP)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(sH + (base + wave * 8) * 128), 16, 0, 0);
+                    dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sH + (base + wave * 8) * 128));
             }
             if (cc == 0) {                               // dy tile: thread = pixel; K*ES bytes of real data per pixel
                 const int py = tid >> 5, px = tid & 31;
                 const char* src = a.dy + (((size_t)n * a.H + y0 + py) * a.W + x0 + px) * a.K * ES;
                 for (int o = 0; o < a.K * ES; o += 16) st16(sD + tid * DPITCH + o, ld16(src + o));
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SGG_WAIT_VM0();
             __syncthreads();
             for (int y = 0; y < HALO_TH; ++y) {           // one k-step = the 32 pixels of tile row y
                 if constexpr (sizeof(T) == 2) {
@@ -2763,10 +2741,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_glds_kernel(WgradArgs a) {
                 const char* sx = ok ? xrow + (uint32_t)(wi * a.C * ES) : zero;
                 const char* sd = dcol_ok ? drow + (uint32_t)(prow * a.K * ES) : zero;
                 const int wrow = (wave * 64) / NCH + RPS * i;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx,
-                                                 (__attribute__((address_space(3))) void*)(sX + wrow * PITCH), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sd,
-                                                 (__attribute__((address_space(3))) void*)(sD + wrow * PITCH), 16, 0, 0);
+                dma16_to_lds(sx, (__attribute__((address_space(3))) void*)(sX + wrow * PITCH));
+                dma16_to_lds(sd, (__attribute__((address_space(3))) void*)(sD + wrow * PITCH));
             }
             return;
         }
@@ -2791,10 +2767,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_glds_kernel(WgradArgs a) {
             }
             // one wave-instruction = 64 lanes x 16 B = 1 KiB of consecutive tile bytes starting at the wave's first row
             const int wrow = (wave * 64) / NCH + RPS * i;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx,
-                                             (__attribute__((address_space(3))) void*)(sX + wrow * PITCH), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sd,
-                                             (__attribute__((address_space(3))) void*)(sD + wrow * PITCH), 16, 0, 0);
+            dma16_to_lds(sx, (__attribute__((address_space(3))) void*)(sX + wrow * PITCH));
+            dma16_to_lds(sd, (__attribute__((address_space(3))) void*)(sD + wrow * PITCH));
         }
     };
 
@@ -2807,7 +2781,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_glds_kernel(WgradArgs a) {
     const int g = lane >> 4, u = lane & 15;
     const int ksteps = pend > pbeg ? (pend - pbeg + BKP - 1) / BKP : 0;
     if (ksteps > 0) stage_tile(0, pbeg);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SGG_WAIT_VM0();
     __syncthreads();
     for (int ks = 0; ks < ksteps; ++ks) {
         const int cur = ks & 1;
@@ -2874,7 +2848,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_glds_kernel(WgradArgs a) {
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SGG_WAIT_VM0();
         __syncthreads();
     }
 
@@ -3243,8 +3217,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
             const int key = wg2_key<bf16>(px) & 15;
             const int trow = px >> 6, tcol = px & 63;
             const char* src = dys + ((((size_t)n * a.H + h0 + trow) * a.W + w0 + tcol) * a.K + n0) * 2 + ((pos ^ key) << 4);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sD + d * 1024), 16, 0, 0);
+            dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sD + d * 1024));
         }
         // x halo: 36 wave-instructions of 8 pixels x 128 B (row k = q / 9, column group q % 9); wave w issues w, w+8, ...
 #pragma unroll
@@ -3261,8 +3234,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
                 wi = wi < 0 ? -wi : (wi >= a.W ? 2 * (a.W - 1) - wi : wi);
             } else ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
             const char* src = ok ? xs + ((((size_t)n * a.H + hi) * a.W + wi) * a.C + c0) * 2 + ((pos ^ key) << 4) : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sX + (k * W9_PITCH + cg * 8) * 128), 16, 0, 0);
+            dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sX + (k * W9_PITCH + cg * 8) * 128));
         }
     };
 
@@ -3294,7 +3266,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
         }
     }
     if (t_beg < t_end) stage_tile(0, t_beg);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SGG_WAIT_VM0();
     __builtin_amdgcn_s_barrier();
     for (int t = t_beg; t < t_end; ++t) {
         const int cur = (t - t_beg) & 1;
@@ -3332,8 +3304,8 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
             for (int j = 0; j < 4; ++j)
                 acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[kk & 1][j], fx[i % 3], acc[tap][j], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SGG_WAIT_VM0();
+        SGG_WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
     }
 
@@ -3402,8 +3374,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_s2_kernel(W9SArgs a) {
             const int px = d * 4 + (lane >> 4), pos = lane & 15;
             const int key = wg2_key<bf16>(px) & 15;
             const char* src = a.dy + ((((size_t)n * a.Ho + ho) * a.Wo + w0 + px) * a.K + n0) * 2 + ((pos ^ key) << 4);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sD + d * 1024), 16, 0, 0);
+            dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sD + d * 1024));
         }
         // x halo: 3 rows x 17 wave-instructions of 8 slots; wave w issues q = w, w+8, ...
 #pragma unroll
@@ -3418,8 +3389,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_s2_kernel(W9SArgs a) {
             const int hi = 2 * ho - a.pad_t + k, wi = 2 * w0 - a.pad_l + col;
             const bool ok = col <= 128 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
             const char* src = ok ? a.x + ((((size_t)n * a.H + hi) * a.W + wi) * a.C + c0) * 2 + ((pos ^ key) << 4) : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sX + (k * W9S_PITCH + sg * 8) * 128), 16, 0, 0);
+            dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sX + (k * W9S_PITCH + sg * 8) * 128));
         }
     };
 
@@ -3450,7 +3420,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_s2_kernel(W9SArgs a) {
         }
     }
     if (t_beg < t_end) stage_tile(0, t_beg);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SGG_WAIT_VM0();
     __builtin_amdgcn_s_barrier();
     for (int t = t_beg; t < t_end; ++t) {
         const int cur = (t - t_beg) & 1;
@@ -3487,8 +3457,8 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_s2_kernel(W9SArgs a) {
             for (int j = 0; j < 4; ++j)
                 acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[kk][j], fx[i % 3], acc[tap][j], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SGG_WAIT_VM0();
+        SGG_WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
     }
 

@@ -463,3 +463,30 @@ def test_cycle_criteria_mse_edge_gradloss(sg):
         assert abs(loss.item() - 5 * l.v) < (1e-5 if dtype == torch.float32 else 1e-3) * 5 * l.v
         close(da.float().cpu().numpy()[..., :3], va.g, dtype, "dgradloss")
         assert float(da.float()[..., 3:].abs().max()) == 0.0
+
+
+def test_timed_launch_hooks_put_events_on_the_kernel_dispatch(sg):
+    """bench.py's measurement hooks (sgg_time_next_launch): an armed event pair is consumed by the main kernel of the next
+    timed-family launch and reads a plausible kernel duration; a call outside the timed families leaves it unused."""
+    import ctypes
+    from sggan_amd import kernels as K, _abi as A
+    s, e = ctypes.c_void_p(), ctypes.c_void_p()
+    A.check(A.lib().sgg_event_create(ctypes.byref(s)), "event_create")
+    A.check(A.lib().sgg_event_create(ctypes.byref(e)), "event_create")
+    g = K.conv_geom(2, 16, 128, 64, 64, 3, 3, 1, "VALID", 1, torch.bfloat16)            # a halo-GEMM shape
+    x = torch.randn(g.x_shape, device="cuda").to(torch.bfloat16)
+    wf, _ = K.pack_weights(torch.randn(3, 3, 64, 64, device="cuda") * 0.05, 64, 64, torch.bfloat16)
+    K.conv_fwd(g, x, wf, None)                                                           # warm (LDS attribute, allocations)
+    A.lib().sgg_time_next_launch(s, e)
+    y = K.conv_fwd(g, x, wf, None)
+    assert A.lib().sgg_time_next_launch(None, None) == 1                                 # consumed
+    torch.cuda.synchronize()
+    ms = ctypes.c_float()
+    A.check(A.lib().sgg_event_elapsed_ms(s, e, ctypes.byref(ms)), "event_elapsed")
+    assert 1e-3 < ms.value < 5.0, ms.value
+    A.lib().sgg_time_next_launch(s, e)
+    K.act_fwd(y, A.ACT_RELU)                                                             # not a timed family
+    assert A.lib().sgg_time_next_launch(None, None) == 0
+    y2 = K.conv_fwd(g, x, wf, None)                                                      # and the disarmed launch is an ordinary one
+    assert torch.equal(y, y2)
+    A.lib().sgg_event_destroy(s); A.lib().sgg_event_destroy(e)

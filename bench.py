@@ -158,6 +158,10 @@ class EventProfiler:
             d = key.desc
             if d.R == 3 and d.C == 256 and d.K == 256 and d.stride == 1 and d.pad_mode == 1:
                 tag = ("res_conv_wgrad_pair", d.R * d.S * d.C, d.K, 2 * d.N * d.Ho * d.Wo)   # two applications, one launch
+        elif name == "conv2d_bwd_weight_pair2" and hasattr(key, "desc"):
+            d = key.desc
+            if d.R == 3 and d.C == 256 and d.K == 256 and d.stride == 1 and d.pad_mode == 1:
+                tag = ("res_conv_wgrad_pair2", d.R * d.S * d.C, d.K, 4 * d.N * d.Ho * d.Wo)   # two networks x two applications, one launch
         elif name in ("instnorm_fwd", "instnorm_fwd_pair", "instnorm_fwd_partial", "instnorm_fwd_partial_pair"):
             shape, has_res = key
             if len(shape) == 4 and shape[3] == 256 and tuple(shape[1:3]) == self.res_hw:

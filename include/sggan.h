@@ -150,6 +150,12 @@ int sgg_conv2d_bwd_weight(const sgg_conv_desc* d, const void* x, const void* dy,
 int sgg_conv2d_bwd_weight_pair_supported(const sgg_conv_desc* d);
 int sgg_conv2d_bwd_weight_pair(const sgg_conv_desc* d, const void* x0, const void* dy0, const void* x1, const void* dy1,
                                float* dw, int C_real, int K_real, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* ... of TWO networks of one architecture, each applied twice (the upstream cycle step's generators): four (x, dy) sets, two dW, ONE
+ * launch in which each network gets half the blocks -- half as many f32 slabs to write and reduce.  Same result as two
+ * sgg_conv2d_bwd_weight_pair calls up to f32 summation order.  Workspace as for one network. */
+int sgg_conv2d_bwd_weight_pair2(const sgg_conv_desc* d, const void* xa0, const void* dya0, const void* xa1, const void* dya1, float* dwa,
+                                const void* xb0, const void* dyb0, const void* xb1, const void* dyb1, float* dwb,
+                                int Cr, int Kr, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- deconv2d: tf.keras.layers.Conv2DTranspose(3x3, s2, 'same') ---- module.py:254,258
  * `d` describes the EQUIVALENT FORWARD CONV whose input is the deconv OUTPUT:

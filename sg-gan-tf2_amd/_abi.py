@@ -60,6 +60,7 @@ SIGNATURES = {
     "sgg_conv2d_bwd_weight": (_i, [_dp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sgg_conv2d_bwd_weight_pair_supported": (_i, [_dp]),
     "sgg_conv2d_bwd_weight_pair": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sgg_conv2d_bwd_weight_pair2": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sgg_deconv2d_fwd_workspace": (_sz, [_dp]),
     "sgg_deconv2d_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _i, _f, _vp, _sz, _vp]),
     "sgg_deconv2d_bwd_data_workspace": (_sz, [_dp]),
@@ -120,6 +121,9 @@ def lib():
 
 class SggError(RuntimeError):
     pass
+
+
+OK, EINVAL, EUNSUPPORTED, ELAUNCH, EWORKSPACE = 0, -1, -2, -3, -4      # sgg_status (include/sggan.h)
 
 
 def check(status: int, what: str = ""):

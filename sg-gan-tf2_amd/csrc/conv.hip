@@ -2869,15 +2869,20 @@ __global__ __launch_bounds__(512) void conv_wgrad_glds_kernel(WgradArgs a) {
 
 // dw[tap][c<Cr][k<Kr] (+)= sum_split ws[split][tap*C + c][k]   (fixed summation tree -> deterministic)
 // One thread per 4 consecutive k (K is a multiple of 8): 16-byte slab reads, 4 independent partial sums in flight.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, float* dw, int taps, int C, int K, int Cr, int Kr, int splits, int accumulate) {
+// dw2 != nullptr: two networks in one launch -- slabs [splits, 2 * splits) of ws sum into dw2
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, float* dw, int taps, int C, int K, int Cr, int Kr, int splits, int accumulate,
+                                                           float* dw2 = nullptr) {
     const int K4 = K / 4;
-    const int64_t total = (int64_t)taps * Cr * K4;
+    const int64_t total1 = (int64_t)taps * Cr * K4, total = dw2 ? 2 * total1 : total1;
     const size_t slab = (size_t)taps * C * K;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += (int64_t)gridDim.x * blockDim.x) {
+        const bool netb = i0 >= total1;
+        const int64_t i = netb ? i0 - total1 : i0;
+        if (netb) dw = dw2;                              // (i0 only grows: once in the second network, always there)
         int k4 = (int)(i % K4);
         int64_t t = i / K4;
         int c = (int)(t % Cr), tap = (int)(t / Cr);
-        const float* src = ws + ((size_t)tap * C + c) * K + k4 * 4;
+        const float* src = ws + (netb ? (size_t)splits * slab : 0) + ((size_t)tap * C + c) * K + k4 * 4;
         // eight independent 16-byte loads in flight per thread (the grid is only ~9 waves per CU: with four the pass ran at 4.8 TB/s),
         // combined in a fixed tree -> deterministic
         f32x4 acc8[8];
@@ -3173,6 +3178,11 @@ struct W9Args {
     float* ws;           // [splits][9*C][K] f32 slabs
     int N, H, W, C, K, reflect;
     int tiles, tiles_per_split;   // tiles counts both pairs
+    // Two NETWORKS of one shape in one launch (the cycle step's G_A->B beside G_B->A): splits [splits_per_net, 2 * splits_per_net)
+    // belong to the second network and read xb / dyb / x2b / dy2b; each network then gets half the blocks, i.e. half the slabs
+    // to write and to reduce for the same work per CU.  splits_per_net >= the grid's split count: one network.
+    const char* xb; const char* dyb; const char* x2b; const char* dy2b;
+    int splits_per_net;
 };
 
 // 16-byte chunk XOR key of halo row `row` (128-byte rows, two per 256-byte bank line): a transposing read touches rows
@@ -3193,17 +3203,23 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
     }
     const int split = lid / otiles, tl = lid - split * otiles;
     const int c0 = (tl / ktiles) * 64, n0 = (tl % ktiles) * 128;
-    const int t_beg = split * a.tiles_per_split;
+    const bool netb = split >= a.splits_per_net;         // second network's blocks (uniform per block)
+    const int nsplit = netb ? split - a.splits_per_net : split;
+    const int t_beg = nsplit * a.tiles_per_split;
     const int t_end = min(a.tiles, t_beg + a.tiles_per_split);
     const int tilesW = a.W / W9_TW, tilesH = a.H >> 1;
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    const char* const X1 = netb ? a.xb : a.x;
+    const char* const D1 = netb ? a.dyb : a.dy;
+    const char* const X2 = netb ? a.x2b : a.x2;
+    const char* const D2 = netb ? a.dy2b : a.dy2;
 
-    const int tiles1 = a.x2 ? a.tiles >> 1 : a.tiles;    // tiles of the first (x, dy) pair
+    const int tiles1 = X2 ? a.tiles >> 1 : a.tiles;      // tiles of the first (x, dy) pair
     auto stage_tile = [&](int stg, int tt) {
         const bool second = tt >= tiles1;
         const int t = second ? tt - tiles1 : tt;
-        const char* xs = second ? a.x2 : a.x;
-        const char* dys = second ? a.dy2 : a.dy;
+        const char* xs = second ? X2 : X1;
+        const char* dys = second ? D2 : D1;
         const int tw = t % tilesW, rest = t / tilesW;
         const int th = rest % tilesH, n = rest / tilesH;
         const int h0 = th * 2, w0 = tw * W9_TW;
@@ -3551,23 +3567,30 @@ static int wgrad_splits(const sgg_conv_desc* d) {
     return (int)sp;
 }
 
-static int run_w9(const sgg_conv_desc* d, const void* x, const void* dy, const void* x2, const void* dy2, float* dw, int Cr, int Kr,
-                  int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+struct W9Net { const void* x; const void* dy; const void* x2; const void* dy2; float* dw; };
+// one network (nb == nullptr), or two networks of the same layer shape sharing the launch: each gets half the splits
+static int run_w9(const sgg_conv_desc* d, const W9Net& na, const W9Net* nb, int Cr, int Kr, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
     const int sp = w9_splits(d);
+    if (nb && (sp & 1)) return SGG_EUNSUPPORTED;
     size_t need9 = (size_t)sp * 9 * d->C * d->K * sizeof(float);
     if (ws_bytes < need9 || !ws) return SGG_EWORKSPACE;
+    const int spn = nb ? sp / 2 : sp;                    // splits per network
     W9Args w;
-    w.x = (const char*)x; w.dy = (const char*)dy; w.x2 = (const char*)x2; w.dy2 = (const char*)dy2; w.ws = (float*)ws;
+    w.x = (const char*)na.x; w.dy = (const char*)na.dy; w.x2 = (const char*)na.x2; w.dy2 = (const char*)na.dy2; w.ws = (float*)ws;
+    w.xb = w.dyb = w.x2b = w.dy2b = nullptr;
+    if (nb) { w.xb = (const char*)nb->x; w.dyb = (const char*)nb->dy; w.x2b = (const char*)nb->x2; w.dy2b = (const char*)nb->dy2; }
+    w.splits_per_net = spn;
     w.N = d->N; w.H = d->H; w.W = d->W; w.C = d->C; w.K = d->K; w.reflect = d->pad_mode == SGG_PAD_REFLECT;
-    w.tiles = w9_tiles(d) * (x2 ? 2 : 1);
-    w.tiles_per_split = (w.tiles + sp - 1) / sp;
+    w.tiles = w9_tiles(d) * (na.x2 ? 2 : 1);
+    w.tiles_per_split = (w.tiles + spn - 1) / spn;
     SGG_LDS_ATTR(conv3x3_wgrad_halo_kernel, 2 * W9_STAGE);
     sgg_launch_timed(conv3x3_wgrad_halo_kernel, dim3((unsigned)(sp * (d->C / 64) * (d->K / 128))), dim3(512), (unsigned)(2 * W9_STAGE), s, w);
     int rc9 = sgg_check_launch();
     if (rc9) return rc9;
-    int64_t total9 = (int64_t)9 * Cr * (d->K / 4);
+    int64_t total9 = (int64_t)9 * Cr * (d->K / 4) * (nb ? 2 : 1);
     int blocks9 = (int)((total9 + 255) / 256); if (blocks9 > 4096) blocks9 = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks9), dim3(256), 0, s, (const float*)ws, dw, 9, d->C, d->K, Cr, Kr, sp, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks9), dim3(256), 0, s, (const float*)ws, na.dw, 9, d->C, d->K, Cr, Kr, spn, accumulate,
+                       nb ? nb->dw : (float*)nullptr);
     return sgg_check_launch();
 }
 
@@ -3599,7 +3622,7 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
         return sgg_check_launch();
     }
     if constexpr (sizeof(T) == 2) {
-        if (w9_ok(d)) return run_w9(d, x, dy, nullptr, nullptr, dw, Cr, Kr, accumulate, ws, ws_bytes, s);   // 3x3 s1: x halo resident, all taps per block
+        if (w9_ok(d)) return run_w9(d, W9Net{x, dy, nullptr, nullptr, dw}, nullptr, Cr, Kr, accumulate, ws, ws_bytes, s);   // 3x3 s1: x halo resident, all taps per block
         if (w9s_ok(d)) {                                  // 3x3 s2: the same with a parity-de-interleaved halo
             const int sp = w9s_splits(d);
             size_t need9 = (size_t)sp * 9 * d->C * d->K * sizeof(float);
@@ -3898,7 +3921,20 @@ int sgg_conv2d_bwd_weight_pair(const sgg_conv_desc* d, const void* x0, const voi
                                int Cr, int Kr, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     if (!desc_ok(d) || !x0 || !dy0 || !x1 || !dy1 || !dw || Cr <= 0 || Kr <= 0 || Cr > d->C || Kr > d->K) return SGG_EINVAL;
     if (!w9_ok(d)) return SGG_EUNSUPPORTED;
-    return run_w9(d, x0, dy0, x1, dy1, dw, Cr, Kr, accumulate, ws, ws_bytes, (hipStream_t)stream);
+    return run_w9(d, W9Net{x0, dy0, x1, dy1, dw}, nullptr, Cr, Kr, accumulate, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ... of TWO networks of one architecture (the cycle step's generators, each applied twice): four (x, dy) sets, two dW, one launch.
+// Each network gets half the blocks, so half as many f32 slabs are written and reduced for the same work per CU; the sums differ
+// from two sgg_conv2d_bwd_weight_pair calls only in f32 summation order (16 partial sums per network instead of 32).
+int sgg_conv2d_bwd_weight_pair2(const sgg_conv_desc* d, const void* xa0, const void* dya0, const void* xa1, const void* dya1, float* dwa,
+                                const void* xb0, const void* dyb0, const void* xb1, const void* dyb1, float* dwb,
+                                int Cr, int Kr, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    if (!desc_ok(d) || !xa0 || !dya0 || !xa1 || !dya1 || !dwa || !xb0 || !dyb0 || !xb1 || !dyb1 || !dwb || Cr <= 0 || Kr <= 0 || Cr > d->C || Kr > d->K)
+        return SGG_EINVAL;
+    if (!w9_ok(d) || (w9_splits(d) & 1)) return SGG_EUNSUPPORTED;
+    const W9Net nb{xb0, dyb0, xb1, dyb1, dwb};
+    return run_w9(d, W9Net{xa0, dya0, xa1, dya1, dwa}, &nb, Cr, Kr, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
 
 size_t sgg_deconv2d_fwd_workspace(const sgg_conv_desc* d) {

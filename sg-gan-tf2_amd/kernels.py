@@ -302,6 +302,28 @@ def conv_wgrad_pair(g: ConvGeom, x0, dy0, x1, dy1, dw, accumulate=False):
     if pr: pr.stop()
 
 
+def conv_wgrad_pair2(g: ConvGeom, net_a, net_b, accumulate=False):
+    """Two networks of one architecture, each applied twice: net = (x0, dy0, x1, dy1, dw); ONE launch, half the slabs per network.
+    Returns False (nothing launched) when the shape has no such form."""
+    assert g.wgrad_pair
+    dwa, dwb = net_a[4], net_b[4]
+    assert dwa.dtype == torch.float32 and dwb.dtype == torch.float32 and dwa.shape == dwb.shape
+    for x0, d0, x1, d1, _ in (net_a, net_b):
+        for x, dy in ((x0, d0), (x1, d1)):
+            assert tuple(x.shape) == g.x_shape and tuple(dy.shape) == g.y_shape
+    ws = workspace(g.ws_wgrad, dwa.device)
+    pr = _prof("conv2d_bwd_weight_pair2", g)
+    if pr: pr.start()
+    rc = A.lib().sgg_conv2d_bwd_weight_pair2(C.byref(g.desc), *[_p(t) for t in net_a], *[_p(t) for t in net_b], dwa.shape[2], dwa.shape[3],
+                                             int(accumulate), _p(ws), ws.numel(), _s())
+    if rc == A.EUNSUPPORTED:
+        if pr: pr.stop()
+        return False
+    A.check(rc, "conv2d_bwd_weight_pair2")
+    if pr: pr.stop()
+    return True
+
+
 def deconv_fwd(g: ConvGeom, x, w_dgrad, bias, act=A.ACT_NONE, leak=0.0, out=None):
     assert tuple(x.shape) == g.x_shape and g.is_deconv
     y = _out(out, g.y_shape, x.dtype, x.device)

@@ -610,8 +610,16 @@ class _PairUnit:
                 for u, sl in halves:
                     K.bias_grad(dxc[sl], u.net.P.g(u.name + "_b"), accumulate=True)
         if param_grads:
-            for u, sl in halves:
-                u.weight_grad(g, x[sl], dxc[sl])
+            # both networks have this layer's first application waiting (pair_wgrads): all four weight gradients in ONE launch
+            pa, pb = ua._pending, ub._pending
+            quad = (ua.kind == "conv" and g.wgrad_pair and ua.net.pair_wgrads and ub.net.pair_wgrads and pa is not None and pb is not None
+                    and pa[0].x_shape == g.x_shape and pb[0].x_shape == g.x_shape)
+            if quad and K.conv_wgrad_pair2(g, (pa[1], pa[2], x[halves[0][1]], dxc[halves[0][1]], PA.g(na + "_w")),
+                                           (pb[1], pb[2], x[halves[1][1]], dxc[halves[1][1]], PB.g(nb + "_w")), accumulate=True):
+                ua._pending = ub._pending = None
+            else:
+                for u, sl in halves:
+                    u.weight_grad(g, x[sl], dxc[sl])
         if not want_dx:
             return None
         if ua.kind == "conv" and ua.geom(x).pair_ok:

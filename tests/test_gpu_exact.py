@@ -165,3 +165,29 @@ def test_mixed_precision_data_gradient_is_exact_f32_at_bench_shape(sg):
     same(dx2, vx.g + add, "mixed dgrad + f32 addend")
     dx3 = K.conv_dgrad(g, dev(dy, torch.bfloat16), wd, dev(np.round(add / 8), torch.bfloat16), out_f32=True)
     same(dx3, vx.g + np.round(add / 8), "mixed dgrad + bf16 addend")
+
+
+def test_two_network_weight_gradient_launch_bit_exact_at_bench_shape(sg):
+    """sgg_conv2d_bwd_weight_pair2: both generators' weight gradients of a residual conv -- four (x, dy) sets of 8 x 64 x 128 x
+    256, two dW -- in one launch, each network on half the blocks.  Integer inputs: both dW must equal the oracle exactly."""
+    from sggan_amd import kernels as K
+    N, H, W, C = 8, 64, 128, 256
+    rng = np.random.default_rng(79)
+    w, b = ints(rng, (3, 3, C, C)), np.zeros(C)
+    sets, exp = [], []
+    for _ in range(4):
+        x, dy = ints(rng, (N, H, W, C)), ints(rng, (N, H, W, C))
+        t = O.Tape()
+        vx, vw, vb = O.Var(x), O.Var(w), O.Var(b)
+        y = O.conv2d(t, vx, vw, vb, 1, "VALID", 1)
+        t.backward([(y, dy)])
+        sets.append((dev(x, torch.bfloat16), dev(dy, torch.bfloat16)))
+        exp.append(vw.g)
+    g = K.conv_geom(N, H, W, C, C, 3, 3, 1, "VALID", 1, torch.bfloat16)
+    assert g.wgrad_pair
+    dwa = torch.full((3, 3, C, C), 3.0, device="cuda")
+    dwb = torch.full((3, 3, C, C), -7.0, device="cuda")
+    ok = K.conv_wgrad_pair2(g, (*sets[0], *sets[1], dwa), (*sets[2], *sets[3], dwb), accumulate=True)
+    assert ok
+    same(dwa, exp[0] + exp[1] + 3.0, "network a")
+    same(dwb, exp[2] + exp[3] - 7.0, "network b")

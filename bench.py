@@ -274,6 +274,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--mixed", type=int, default=0, help="1: bf16 storage with the f32 activation-gradient chain through the residual blocks (sggan mixed=True)")
+    ap.add_argument("--no-reference-leg", action="store_true", help="skip the reference-mode step timed beside the cycle headline (profiling: keeps the kernel statistics to the cycle step)")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step from captured HIP graphs (default); 0: eager per-launch dispatch from Python")
     a = ap.parse_args()
 
@@ -416,7 +417,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline_cycle(a.height, a.width, 19) if a.mode == "cycle" else cpu_baseline(a.height, a.width, 19)
         else:
             line["cpu_baseline"] = None
-        line["_pending_reference"] = (world == 1 and a.mode == "cycle")
+        line["_pending_reference"] = (world == 1 and a.mode == "cycle" and not a.no_reference_leg)
         if line.pop("_pending_reference"):
             # the literal reference step (1 G + 1 D) beside the headline, same shapes, short run
             K.PROFILE = None

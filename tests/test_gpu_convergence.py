@@ -38,20 +38,23 @@ def test_bf16_and_mixed_train_like_f32_over_200_steps():
         assert np.isfinite(g).all() and np.isfinite(d).all()
     gf, df = curves["f32"]
     gt, dtw = curves["f32twin"]
-    drift_g, drift_d = np.abs(gt - gf).mean(), np.abs(dtw - df).mean()
+    E = 15                                             # samples of the smooth phase (steps 10 .. 150)
+    drift_g, drift_d = np.abs(gt - gf)[:E].mean(), np.abs(dtw - df)[:E].mean()
     print("gen loss every 10 steps  f32  ", np.round(gf, 3).tolist())
     print("disc loss every 10 steps f32  ", np.round(df, 3).tolist())
-    print(f"f32 vs perturbed f32: mean |gen loss diff| {drift_g:.4f}, mean |disc loss diff| {drift_d:.4f}")
+    print(f"f32 vs perturbed f32, first {E} samples: mean |gen loss diff| {drift_g:.4f}, mean |disc loss diff| {drift_d:.4f}; "
+          f"whole run: {np.abs(gt - gf).mean():.4f}, {np.abs(dtw - df).mean():.4f}; max |gen loss diff| {np.abs(gt - gf).max():.3f}")
     for mode in ("bf16", "mixed"):
         g, d = curves[mode]
         print(f"gen loss every 10 steps  {mode:5s}", np.round(g, 3).tolist())
         print(f"disc loss every 10 steps {mode:5s}", np.round(d, 3).tolist(), f"mean |diff| {np.abs(d - df).mean():.4f}")
-        # the adversarial game on a fixed batch: the generator loss first falls (~20 %), then rises again as the discriminators
-        # catch up -- the reduced-precision runs must follow the f32 trajectory (GAN dynamics are chaotic step to step, so
-        # the bounds are on the curves, not on single steps)
+        # The adversarial game on a fixed batch: the generator loss falls (~20 %) for ~120 steps, then rises again as the
+        # discriminators catch up, and from ~step 160 the two sides oscillate -- a regime in which two f32 runs that differ by 1e-6
+        # in their parameters already decorrelate (the twin's drift is printed above).  So: through the smooth phase the
+        # reduced-precision runs must FOLLOW the f32 trajectory; over the whole run they must stay in its range.
         assert g.min() < 0.85 * g[0] and gf.min() < 0.85 * gf[0]
-        assert np.abs(g - gf).mean() < 0.05 * gf.mean(), (mode, np.abs(g - gf).mean(), gf.mean())
-        assert np.abs(g - gf).max() < 0.15 * gf.mean(), (mode, np.abs(g - gf).max(), gf.mean())
-        # the discriminator loss is small and oscillates: bound it by the larger of 25 % of its mean and three times the drift of
-        # the perturbed f32 run
-        assert np.abs(d - df).mean() < max(0.25 * max(df.mean(), 0.05), 3.0 * drift_d), (mode, np.abs(d - df).mean(), df.mean(), drift_d)
+        assert np.abs(g - gf)[:E].mean() < max(0.02 * gf[:E].mean(), 3.0 * drift_g), (mode, np.abs(g - gf)[:E].mean(), gf[:E].mean(), drift_g)
+        assert np.abs(g - gf)[:E].max() < 0.05 * gf[:E].mean(), (mode, np.abs(g - gf)[:E].max(), gf[:E].mean())
+        assert np.abs(d - df)[:E].mean() < max(0.25 * max(df[:E].mean(), 0.05), 3.0 * drift_d), (mode, np.abs(d - df)[:E].mean(), df[:E].mean(), drift_d)
+        assert 0.7 * gf.min() < g.min() and g.max() < 1.3 * gf.max(), (mode, g.min(), g.max(), gf.min(), gf.max())
+        assert d.max() < 1.0

@@ -79,24 +79,39 @@ def set_inputs(model, N, H, W, seed):
         model.real_B, model.seg_B, model.mask_B = b[0], b[1], b[2]
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_traffic.json: FETCH_SIZE doubled per
-    MI355X_MICROARCH.md + WRITE_SIZE, separate --pmc passes on tools/bench_conv.py); None if not collected."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
-            return json.load(f)[kernel]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json")        # newest first
+
+
+def measured_traffic(kernel, gflop_per_launch=None):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_traffic.json: FETCH_SIZE doubled per
+    MI355X_MICROARCH.md + WRITE_SIZE, separate --pmc passes on tools/bench_conv.py).  Returns (bytes, note); an entry collected
+    on a launch of another size (its "gflop_per_launch") is scaled to this one and the note says so; (None, None) if not collected."""
+    for name in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                e = json.load(f)[kernel]
+        except Exception:
+            continue
+        b = e["hbm_bytes_per_launch"]                       # (helper kernels of the call are listed separately in the file)
+        g = e.get("gflop_per_launch", 77.309411328)
+        note = f"FETCH_SIZE (doubled, gfx950) + WRITE_SIZE per launch of the main kernel, profiles/{name}"
+        if gflop_per_launch is not None and abs(g - gflop_per_launch) > 1e-3 * g:
+            b = b * gflop_per_launch / g
+            note += f" (collected on a {g:.1f} GFLOP launch, scaled to this launch's {gflop_per_launch:.1f})"
+        return b, note
+    return None, None
 
 
 def measured_in_traffic(algorithmic_bytes):
     """HBM bytes of the instance-norm apply pass per algorithmic byte (profiles/r02_in_traffic.json: 33.55 MB tensor read + written),
     scaled to `algorithmic_bytes`; None if not collected."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_in_traffic.json")) as f:
-            return json.load(f)["in_apply_kernel_fwd"]["hbm_bytes_per_launch"] / (2 * 33554432.0) * algorithmic_bytes
-    except Exception:
-        return None
+    for name in ("r03_in_traffic.json", "r02_in_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["in_apply_kernel_fwd"]["hbm_bytes_per_launch"] / (2 * 33554432.0) * algorithmic_bytes
+        except Exception:
+            continue
+    return None
 
 
 class EventProfiler:
@@ -137,6 +152,7 @@ class EventProfiler:
                 self.store.append((self.s, self.e))
             else:
                 self.prof.unused += 1
+                self.A.lib().sgg_event_destroy(self.s); self.A.lib().sgg_event_destroy(self.e)
 
     def __call__(self, name, key):
         if self.mode == "off":
@@ -182,14 +198,17 @@ class EventProfiler:
                 v = ctypes.c_float()
                 A.check(A.lib().sgg_event_elapsed_ms(s, e, ctypes.byref(v)), "event_elapsed")
                 ms.append(v.value)
+                A.lib().sgg_event_destroy(s); A.lib().sgg_event_destroy(e)
             if ms:
                 out[tag] = (float(np.mean(ms)), len(ms))
+        self.records = {}
         return out
 
 
-def cpu_baseline_cycle(H, W, seed, budget_s=70.0):
-    """PyTorch-CPU f32 restatement of the cycle-mode step at N=1 (kind "port"): 1 warm-up, then the median of up to 3 timed
-    steps -- as many as fit a wall-clock budget (one step of this shape takes ~15 s on the GPU node's host cores)."""
+def cpu_baseline_cycle(H, W, seed, budget_s=40.0):
+    """PyTorch-CPU f32 restatement of the cycle-mode step at N=1 (kind "port"): 1 warm-up, then the median of up to 2 timed
+    steps -- as many as fit a 40 s wall-clock budget (one step of this shape takes ~15 s on the GPU node's host cores, the
+    warm-up ~18 s), so the driver's GPU lease is not spent on the CPU leg."""
     from oracle import torch_restatement as T
     from oracle import sggan_oracle as O
     rng = np.random.default_rng(seed)
@@ -204,13 +223,13 @@ def cpu_baseline_cycle(H, W, seed, budget_s=70.0):
     S.step(*inputs)
     warm = time.time() - t0
     times = []
-    while len(times) < 3 and (not times or (time.time() - t0) + float(np.median(times)) < budget_s):
+    while len(times) < 2 and (not times or (time.time() - t0) + float(np.median(times)) < budget_s):
         t1 = time.time()
         S.step(*inputs)
         times.append(time.time() - t1)
     dt = float(np.median(times))
     return {"value": 1.0 / dt, "unit": "images/sec", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"median of {len(times)} timed cycle-mode steps (2G+2D) of N=1 {W}x{H} f32 after 1 warm-up ({warm:.1f} s), as many "
+            "sample": f"median of {len(times)} timed cycle-mode step(s) (2G+2D) of N=1 {W}x{H} f32 after 1 warm-up ({warm:.1f} s), as many "
                       f"as fit a {budget_s:.0f} s budget (PyTorch-CPU restatement, oracle/torch_restatement.py CycleStep; not TF2); "
                       f"step times {[round(t, 2) for t in times]} s; os.cpu_count()={os.cpu_count()}",
             "gflops": step_gflop_per_image(H, W, "cycle") / dt}
@@ -276,6 +295,8 @@ def main():
     ap.add_argument("--mixed", type=int, default=0, help="1: bf16 storage with the f32 activation-gradient chain through the residual blocks (sggan mixed=True)")
     ap.add_argument("--no-reference-leg", action="store_true", help="skip the reference-mode step timed beside the cycle headline (profiling: keeps the kernel statistics to the cycle step)")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step from captured HIP graphs (default); 0: eager per-launch dispatch from Python")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the short f32 (the reference's precision) run of the same step reported as f32_step")
+    ap.add_argument("--lib", default=None, help="A/B timing: bind this build of the library instead of the in-tree libsggan.so")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -295,9 +316,11 @@ def main():
             torch.cuda.synchronize()
 
     import sggan_amd
+    if a.lib:
+        sggan_amd._abi.use_library(a.lib)
     from sggan_amd import kernels as K
-    def make_model(mode):
-        m = sggan_amd.sggan(sggan_amd.default_args(dtype=a.dtype, device=f"cuda:{local}", image_height=a.height,
+    def make_model(mode, dtype=None):
+        m = sggan_amd.sggan(sggan_amd.default_args(dtype=dtype or a.dtype, device=f"cuda:{local}", image_height=a.height,
                                                    image_width=a.width, batch_size=a.batch, cycle=(mode == "cycle"), graph=bool(a.graph), mixed=bool(a.mixed)))
         if dist is not None:
             m.enable_data_parallel()
@@ -389,18 +412,31 @@ def main():
                "launch stream, every launch of this kernel inside the timed region"
                + (f" (its last {eager_tail} steps, which are dispatched eagerly: events cannot be read back from inside a replayed HIP graph)" if a.graph else "")
                + "; helper launches of the same call (side-tensor gather, slab reduce, norm finalize) are not in the span")
-        if "res_conv_fwd" in kt:
-            k = kt["res_conv_fwd"]
-            t8 = measured_traffic("res_conv_fwd")                         # PMC passes ran the 8-image launch (77.3 GFLOP)
-            line["roofline"] = {"bound": "mfma", "kernel": "conv3x3_halo_gemm_kernel<FWD, STATS> (bf16, 256x256 tile, 8 waves, input halo resident in LDS; 3x3 C=256 residual-block conv; "
-                                          "in the cycle step one launch covers the stacked images of both generators -- gflop_per_launch says how many; the timed "
-                                          "launch also computes the following instance norm's per-channel sums in its epilogue, ~4 us, not counted in the FLOPs)",
-                                "achieved": k["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                "frac": k["tflops"] / PEAK_BF16_TFLOPS,
-                                "traffic": None if t8 is None else t8 * k["gflop_per_launch"] / 77.309411328,
-                                "traffic_note": "FETCH_SIZE (doubled, gfx950) + WRITE_SIZE of the 8-image launch (profiles/r02_traffic.json), scaled to this launch's image count",
-                                "avg_launch_ms": k["avg_ms"], "launches_timed": k["launches"], "gflop_per_launch": k["gflop_per_launch"],
-                                "timing": how}
+        # the three residual-block GEMM families; `roofline` is the one with the largest share of the timed steps
+        fam = {"res_conv_fwd": "conv3x3_halo_gemm_kernel<FWD, STATS, PAIR> -- 3x3 C=256 residual-block conv forward (bf16, 256x256 tile, 8 waves, "
+                               "input halo resident in LDS); also computes the following instance norm's per-channel sums in its epilogue (~4 us, not in the FLOPs)",
+               "res_conv_dgrad": "conv3x3_halo_gemm_kernel<DGRAD, REFLECT, PAIR> -- data gradient of the same conv incl. MirrorPadGrad (virtual rows + column "
+                                 "patches from fold_halo_gather_kernel, a ~7 us helper launch not in the span) and the skip-gradient addend in its epilogue",
+               "res_conv_wgrad_pair2": "conv3x3_wgrad_halo_kernel -- weight gradient of the same conv, all nine taps per block; in the cycle step ONE launch covers both "
+                                       "generators x both applications (sgg_conv2d_bwd_weight_pair2); the f32 slab reduce is a helper launch not in the span",
+               "res_conv_wgrad_pair": "conv3x3_wgrad_halo_kernel (two applications of one generator per launch)",
+               "res_conv_wgrad": "conv3x3_wgrad_halo_kernel (one application per launch)"}
+        roofs = {}
+        for name in fam:
+            if name not in kt:
+                continue
+            k = kt[name]
+            tr, tnote = measured_traffic(name if name != "res_conv_wgrad_pair" else "res_conv_wgrad", k["gflop_per_launch"])
+            roofs[name] = {"bound": "mfma", "kernel": fam[name] + "; in the cycle step one launch covers the stacked images of both generators -- "
+                                                                   "gflop_per_launch says how many",
+                           "achieved": k["tflops"], "peak": PEAK_BF16_TFLOPS if a.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
+                           "frac": k["tflops"] / (PEAK_BF16_TFLOPS if a.dtype == "bf16" else 157.3), "traffic": tr, "traffic_note": tnote,
+                           "avg_launch_ms": k["avg_ms"], "launches_timed": k["launches"], "gflop_per_launch": k["gflop_per_launch"],
+                           "share_of_timed_steps_ms": k["avg_ms"] * k["launches"], "timing": how}
+        if roofs:
+            top = max(roofs, key=lambda n: roofs[n]["share_of_timed_steps_ms"])
+            line["roofline"] = dict(roofs[top], name=top, why="largest total time among the step's kernels (residual-block GEMM families) in the timed launches")
+            line["roofline_others"] = {n: r for n, r in roofs.items() if n != top}
         else:
             line["roofline"] = None
         if "res_instnorm_apply_fwd" in kt:
@@ -417,8 +453,31 @@ def main():
             line["cpu_baseline"] = cpu_baseline_cycle(a.height, a.width, 19) if a.mode == "cycle" else cpu_baseline(a.height, a.width, 19)
         else:
             line["cpu_baseline"] = None
-        line["_pending_reference"] = (world == 1 and a.mode == "cycle" and not a.no_reference_leg)
-        if line.pop("_pending_reference"):
+        if world == 1 and a.dtype != "f32" and not a.no_f32_leg:
+            # the same step at the reference's own precision (Keras float32 end to end; module.py layers are default-dtype):
+            # f32 storage, v_mfma_f32_16x16x4_f32 (1/16 of the bf16 matrix rate), same kernels otherwise; short run
+            K.PROFILE = None
+            model._program = None
+            del model
+            torch.cuda.empty_cache()
+            m32 = make_model(a.mode, "f32")
+            for _ in range(2):
+                m32.train_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n32 = 4
+            for _ in range(n32):
+                m32.train_step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n32
+            gl32, dl32 = m32.losses()
+            line["f32_step"] = {"images_per_sec": a.batch / dt, "ms_per_step": 1e3 * dt, "steps": n32, "dtype": "f32",
+                                "step_tflops": a.batch / dt * gflop_img / 1e3, "step_frac_of_f32_mfma_peak": a.batch / dt * gflop_img / 1e3 / 157.3,
+                                "gen_loss": gl32, "disc_loss": dl32,
+                                "what": f"the same {a.mode}-mode step, same shapes, f32 storage and f32 MFMA (the reference trains in float32): "
+                                        "the same-precision-as-the-reference number beside the bf16 headline"}
+            model = m32
+        if world == 1 and a.mode == "cycle" and not a.no_reference_leg:
             # the literal reference step (1 G + 1 D) beside the headline, same shapes, short run
             K.PROFILE = None
             model._program = None

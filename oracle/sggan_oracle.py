@@ -311,10 +311,51 @@ def instance_norm(tape, x: Var, gamma: Var, beta: Var, eps=1e-3) -> Var:
     return y
 
 
+class KinkPolicy:
+    """Which side of a ReLU / LeakyReLU kink an element is on, when that is not decidable at float32 precision.
+
+    The train step is piecewise linear in its activations: an element whose pre-activation is within float32 rounding of
+    zero takes slope 1 in one correct implementation and slope 0 (0.3) in another, and that one difference reaches every
+    gradient behind it at full size (tools/diag_d_f32.py: a pre-activation of 5e-7 moved D's gradients by 3e-4 of their
+    norm).  With ~5 M activations per step some such elements always exist, so no seed avoids them.  Under a policy, elements
+    with |pre-activation| < ``margin`` are AMBIGUOUS: for them the oracle takes the branch the implementation under test
+    took (``branches[k]``: a boolean array per relu / lrelu call, in call order: True = the positive side); everywhere else it
+    keeps its own float64 decision and counts a disagreement as an error of the implementation (``disagree_outside``).  The
+    result is the exact float64 gradient of the same linear piece, which a float32 implementation must then match to
+    float32 accuracy -- with the reference's own slopes."""
+
+    def __init__(self, margin, branches=None):
+        self.margin, self.branches = float(margin), branches
+        self.calls = self.ambiguous = self.overridden = self.disagree_outside = self.elements = 0
+
+    def decide(self, pre):
+        pos = pre > 0
+        amb = np.abs(pre) < self.margin
+        k, self.calls = self.calls, self.calls + 1
+        self.ambiguous += int(amb.sum())
+        self.elements += pre.size
+        if self.branches is not None:
+            ext = np.asarray(self.branches[k], bool)
+            assert ext.shape == pos.shape, (k, ext.shape, pos.shape)
+            diff = ext != pos
+            self.disagree_outside += int((diff & ~amb).sum())
+            self.overridden += int((diff & amb).sum())
+            pos = np.where(amb, ext, pos)
+        return pos
+
+
+KINKS = None        # a KinkPolicy while a test evaluates the oracle kink-aware; None: plain float64 decisions
+
+
+def _positive(pre):
+    return KINKS.decide(pre) if KINKS is not None else pre > 0
+
+
 def relu(tape, x: Var) -> Var:
     """tf.keras.layers.Activation('relu') (module.py:213,234,238,242,256,260)."""
-    y = Var(np.maximum(x.v, 0.0))
-    tape.record(y, lambda gy: x.acc(gy * (x.v > 0)))
+    pos = _positive(x.v)
+    y = Var(np.where(pos, x.v, 0.0))
+    tape.record(y, lambda gy: x.acc(gy * pos))
     return y
 
 
@@ -322,8 +363,9 @@ def lrelu(tape, x: Var, leak=0.3) -> Var:
     """tf.keras.layers.LeakyReLU() (module.py:285-309), [3P] default alpha=0.3.
     ``ops.lrelu`` (ops.py:36-37): max(x, leak*x) with leak=0.2 -- same function
     for 0<leak<1; pass leak to get it."""
-    y = Var(np.where(x.v > 0, x.v, leak * x.v))
-    tape.record(y, lambda gy: x.acc(gy * np.where(x.v > 0, 1.0, leak)))
+    pos = _positive(x.v)
+    y = Var(np.where(pos, x.v, leak * x.v))
+    tape.record(y, lambda gy: x.acc(gy * np.where(pos, 1.0, leak)))
     return y
 
 

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SGG_LIB_PATH") or os.path.join(_HERE, "libsggan.so")   # override: A/B timing of two builds
+LIB_PATH = os.path.join(_HERE, "libsggan.so")      # the package reads no environment; tools pick another build with use_library()
 
 SGG_F32, SGG_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
@@ -41,6 +41,7 @@ SIGNATURES = {
     "sgg_event_destroy": (_i, [_vp]),
     "sgg_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     "sgg_time_next_launch": (_i, [_vp, _vp]),
+    "sgg_stream_capture_nodes": (_i, [_vp, C.POINTER(C.c_int)]),
     "sgg_pack_conv_weights": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sgg_pack_conv_weights_batch": (_i, [_vp, _i, _i64, _i, _vp]),
     "sgg_conv2d_fwd_workspace": (_sz, [_dp]),
@@ -101,6 +102,15 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+def use_library(path):
+    """Bind another build of the library (an A/B variant or the -DSGG_LAB build that tools/ use) instead of the in-tree
+    libsggan.so.  Must be called before the first kernel call; the training path never calls it."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_library() after the library was loaded")
+    LIB_PATH = os.path.abspath(path)
 
 
 def lib():

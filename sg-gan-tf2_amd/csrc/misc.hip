@@ -546,6 +546,21 @@ int sgg_time_next_launch(void* start, void* stop) {
     return consumed;                                     // disarming (NULL, NULL) tells whether the armed pair was used: 1 / 0
 }
 
+int sgg_stream_capture_nodes(void* stream, int* n) {
+    if (!n) return SGG_EINVAL;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    hipGraph_t graph = nullptr;
+    const hipGraphNode_t* deps = nullptr;
+    size_t ndeps = 0;
+    if (hipStreamGetCaptureInfo_v2((hipStream_t)stream, &st, &id, &graph, &deps, &ndeps) != hipSuccess) { (void)hipGetLastError(); return SGG_ELAUNCH; }
+    if (st != hipStreamCaptureStatusActive) { *n = -1; return SGG_OK; }
+    size_t total = ndeps;                                // fallback: the capture's current dependency set (0 before the first node)
+    if (graph && hipGraphGetNodes(graph, nullptr, &total) != hipSuccess) { (void)hipGetLastError(); total = ndeps; }
+    *n = (int)total;
+    return SGG_OK;
+}
+
 const char* sgg_strerror(int status) {
     switch (status) {
         case SGG_OK: return "SGG_OK";

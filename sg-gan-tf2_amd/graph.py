@@ -14,7 +14,11 @@ buffers before a replay; Adam reads its step number from a device counter (``sgg
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
+
+from . import _abi as A
 
 
 class StepProgram:
@@ -25,6 +29,8 @@ class StepProgram:
         self._pool = None
         self._g = None
         self.n_graphs = 0
+        self.keep = []             # tensors allocated OUTSIDE the capture pool whose addresses the recorded launches carry
+                                   # (the shared scratch workspace, per-network scratch vectors): alive as long as the program
 
     # ---- recording -------------------------------------------------------------------------------------------------
     def _open(self):
@@ -40,6 +46,13 @@ class StepProgram:
         self.items.append(("graph", self._g))
         self.n_graphs += 1
         self._g = None
+
+    def _segment_is_empty(self):
+        """No launch has been captured into the open segment yet (hipStreamGetCaptureInfo through the C ABI)."""
+        n = C.c_int(0)
+        A.check(A.lib().sgg_stream_capture_nodes(C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), C.byref(n)),
+                "stream_capture_nodes")
+        return n.value == 0
 
     def record(self, body):
         """Capture ``body()`` (kernel launches on the current stream + ``host()`` cut points).  Kernels are NOT executed."""
@@ -70,9 +83,13 @@ class StepProgram:
 
     def host(self, fn):
         """A host-side action in program order.  While recording: closes the current graph segment, stores ``fn`` and
-        opens the next segment (``fn`` is not called).  Otherwise calls it."""
+        opens the next segment (``fn`` is not called); a host action that follows another with no launch in between joins its cut.
+        Otherwise calls it."""
         if not self.capturing:
             return fn()
+        if self._segment_is_empty():
+            self.items.append(("host", fn))          # consecutive host actions share one cut: no empty graph in between
+            return None
         self._close()
         self.items.append(("host", fn))
         self._open()

@@ -29,7 +29,8 @@ def default_args(**over):
     a = dict(batch_size=1, image_height=128, image_width=128, input_nc=3, output_nc=3, ngf=64, ndf=64,
              segment_class=34, beta1=0.5, lr=0.0002, L1_lambda=10.0, Lg_lambda=5.0, use_resnet=True, use_pix2pix=False,
              use_lsgan=True, ratio_gan2seg=10, max_size=50, phase="train", dataset_dir="city",
-             dtype="bf16", device="cuda", n_blocks=9, seed=19, graph=False, mixed=False, paired=True)
+             dtype="bf16", device="cuda", n_blocks=9, seed=19, graph=False, mixed=False, paired=True,
+             fuse_in_stats=True, fuse_in_bwd=False, g_buckets=3, keep_tapes=False)
     a.update(over)
     return SimpleNamespace(**a)
 
@@ -100,6 +101,16 @@ class sggan(object):
         self.mixed = bool(g("mixed", False)) and self.dtype == torch.bfloat16
         for net in self.networks():
             net.mixed = self.mixed
+            # conv epilogue -> norm statistics (on), data-gradient epilogue -> norm-backward sums (opt-in; module.py)
+            net.fuse_in_stats, net.fuse_in_bwd = bool(g("fuse_in_stats", True)), bool(g("fuse_in_bwd", False))
+        # data parallel: each generator's gradient buffer is exchanged as this many contiguous layer-group buckets, launched
+        # in backward-completion order so that all but the last overlap the rest of the backward pass
+        self.g_buckets = max(1, int(g("g_buckets", 3)))
+        # diagnostics: keep the last step's forward records (saved activations) reachable as ``self.tapes`` -- the parity tests
+        # read from them which side of each ReLU / LeakyReLU kink the kernels took (tests/kink_helpers.py).  Off: they are dropped
+        # when the step returns, so their memory is reused at once.
+        self.keep_tapes = bool(g("keep_tapes", False))
+        self.tapes = None
         # HIP-graph replay of the step (graph.py): recorded at the first train_step after enable_graph()
         self.use_graph = bool(g("graph", False))
         self._program = None
@@ -123,15 +134,40 @@ class sggan(object):
         path; while the step is being recorded it ends the current HIP-graph segment and is replayed between segments."""
         return K.host(fn)
 
-    def _allreduce(self, net):
-        """Launch the all-reduce of one network's gradient bucket; the returned handle's wait() orders the stream."""
+    def _allreduce(self, net, lo=None, hi=None, handle=None):
+        """Launch the all-reduce of one network's gradient bucket (the whole flat buffer, or its [lo, hi) range); the
+        returned handle's wait() orders the stream behind every bucket launched on it."""
         if self._dp is None:
             return None
-        h = _PendingReduce(self)
+        h = handle if handle is not None else _PendingReduce(self)
+        buf = net.P.grad if lo is None else net.P.grad[lo:hi]
         def launch():
-            h.work = self._dp.allreduce_async(net.P.grad)
+            h.works.append(self._dp.allreduce_async(buf))
         self._host(launch)
         return h
+
+    def _bucketed_allreduce(self, nets):
+        """(on_unit_done, handles) for the LAST backward pass of the generator(s) ``nets`` this step: each network's flat
+        gradient buffer is cut into ``g_buckets`` contiguous layer groups (module.bucket_plan); a group's all-reduce is launched
+        as soon as the backward of its first layer -- weight gradient included -- has been queued, i.e. while the layers in front
+        of it are still being differentiated.  Networks that run in lockstep (the paired cycle step) share the host action."""
+        if self._dp is None:
+            return None, [None] * len(nets)
+        plans = [{first: (lo, hi) for first, lo, hi in net.bucket_plan(self.g_buckets)} for net in nets]
+        handles = [_PendingReduce(self) for _ in nets]
+
+        def on_unit_done(name):
+            ready = [(net, h, plan[name]) for net, h, plan in zip(nets, handles, plans) if name in plan]
+            if not ready:
+                return
+            pend = [n for net, _, _ in ready for n in net.pending_wgrads()]
+            assert not pend or name != "c1", f"weight gradients still deferred at the end of the backward pass: {pend}"
+            bufs = [(h, net.P.grad[lo:hi]) for net, h, (lo, hi) in ready]
+            def launch():
+                for h, buf in bufs:
+                    h.works.append(self._dp.allreduce_async(buf))
+            self._host(launch)
+        return on_unit_done, handles
 
     # ------------------------------------------------------------------ HIP-graph replay (graph.py)
     def enable_graph(self, flag=True):
@@ -178,6 +214,8 @@ class sggan(object):
         if self._program is None:
             self._record()
         self._program.replay()
+        for n in self.networks():
+            n.P.version += 1                       # the replayed Adam changed the parameters: eager callers must re-pack
         return self.gen_loss, self.disc_loss
 
     def _record(self):
@@ -200,6 +238,10 @@ class sggan(object):
                 prog.record(self._step_body)
             finally:
                 K._RECORDER = None
+            # addresses baked into the recorded launches that do not come from the capture pool: the shared scratch workspace
+            # and the networks' scratch vectors (allocated by the eager warm-up).  The program keeps them alive, so a later,
+            # larger workspace request elsewhere in the process cannot hand their memory to another tensor under a replay.
+            prog.keep = K.workspace_refs() + [n._scratch for n in nets if n._scratch is not None]
             self._program = prog
         finally:
             K.PROFILE = hook
@@ -247,8 +289,8 @@ class sggan(object):
         # gen_tape.gradient(gen_loss, G vars)    (:196): through D's data path, then G
         dfake = D.backward(tDf, d_fake_g, want_dx=True, param_grads=False)
         dfake = K.add(dfake, dfake_l1)
-        G.backward(tG, dfake, want_dx=False, param_grads=True)
-        hG = self._allreduce(G)
+        hook, (hG,) = self._bucketed_allreduce((G,))
+        G.backward(tG, dfake, want_dx=False, param_grads=True, on_unit_done=hook)
 
         scale = 1.0 / self._world
         if hD is not None:
@@ -260,6 +302,8 @@ class sggan(object):
         self._fake_internal = fake
         self.fake_A = _LazyUnpad(fake, self.output_c_dim)
         self.da_real, self.da_fake = da_real, da_fake
+        if self.keep_tapes:
+            self.tapes = {"G": tG, "D_real": tDr, "D_fake": tDf}
         return self.gen_loss, self.disc_loss
 
     def networks(self):
@@ -348,12 +392,12 @@ class sggan(object):
         d_fA = K.add(d_fA, Gab.backward(t2, d_cycB, want_dx=True))
         d_fB = K.add(d_fB, Db.backward(tDBf, gB_g, want_dx=True, param_grads=False))
         d_fA = K.add(d_fA, Da.backward(tDAf, gA_g, want_dx=True, param_grads=False))
-        Gba.backward(t3, d_fA)
-        Gba.flush_wgrads(); Gba.pair_wgrads = False
-        hGba = self._allreduce(Gba)
-        Gab.backward(t1, d_fB)
+        hook, (hGba,) = self._bucketed_allreduce((Gba,))
+        Gba.backward(t3, d_fA, on_unit_done=hook)               # second application: the paired weight gradients run here
+        Gba.flush_wgrads(); Gba.pair_wgrads = False             # (nothing is left to flush unless a partner never came)
+        hook, (hGab,) = self._bucketed_allreduce((Gab,))
+        Gab.backward(t1, d_fB, on_unit_done=hook)
         Gab.flush_wgrads(); Gab.pair_wgrads = False
-        hGab = self._allreduce(Gab)
 
         scale = 1.0 / self._world
         for opt, h in ((self.d_optim, hDa), (self.d_optim_B, hDb), (self.g_optim_BA, hGba), (self.g_optim, hGab)):
@@ -369,7 +413,10 @@ class sggan(object):
         translation directions on the batch dimension -- [real_A; real_B] -> [fake_B; fake_A] -> [cyc_A; cyc_B] through
         (G_A->B, G_B->A) then (G_B->A, G_A->B); the fakes through (D_B, D_A), the reals through (D_A, D_B).  Convolutions still
         run per network; instance norms, activations and gradient joins run once per pair over twice the bytes.  Same kernels
-        per image, same accumulation order per network as _train_step_cycle: results are bit-identical to it."""
+        per image, same accumulation order per network as _train_step_cycle: losses, images, data gradients and the
+        discriminators' parameter gradients are bit-identical to it; the generators' 3x3 weight gradients, where both networks
+        share a launch (sgg_conv2d_bwd_weight_pair2: 16 split slabs per network instead of 32), are equal up to f32 summation
+        order (held to 1e-5 of the tensor norm by the tests)."""
         Gab, Gba, Da, Db = self.generator, self.generator_BA, self.discriminator, self.discriminator_B
         if getattr(self, "_pairs", None) is None:
             self._pairs = (GeneratorPair(Gab, Gba), GeneratorPair(Gba, Gab), DiscriminatorPair(Db, Da), DiscriminatorPair(Da, Db))
@@ -417,10 +464,13 @@ class sggan(object):
         Gab.pair_wgrads = Gba.pair_wgrads = self.pair_wgrads
         d_f = K.add(d_f, Gp2.backward(t2, d_cyc, want_dx=True))
         d_f = K.add(d_f, Dpf.backward(tDf, g_g, want_dx=True, param_grads=False))
-        Gp1.backward(t1, d_f)
-        Gba.flush_wgrads(); Gab.flush_wgrads()
+        # second application of both generators: every deferred weight gradient runs inside this pass, and each layer group's
+        # all-reduce is launched as soon as the group is complete -- only the last group's exchange has no backward work left
+        # to hide behind (the four Adam launches run under it)
+        hook, (hGab, hGba) = self._bucketed_allreduce((Gab, Gba))
+        Gp1.backward(t1, d_f, on_unit_done=hook)
+        Gba.flush_wgrads(); Gab.flush_wgrads()                  # (nothing is left to flush unless a partner never came)
         Gab.pair_wgrads = Gba.pair_wgrads = False
-        hGba, hGab = self._allreduce(Gba), self._allreduce(Gab)
 
         scale = 1.0 / self._world
         for opt, h in ((self.d_optim, hDa), (self.d_optim_B, hDb), (self.g_optim_BA, hGba), (self.g_optim, hGab)):
@@ -429,6 +479,8 @@ class sggan(object):
             opt.apply_gradients(grad_scale=scale)
         self.fake_A, self.fake_B = _LazyUnpad(f1[hi], self.input_c_dim), _LazyUnpad(f1[lo], C)
         self.cyc_A, self.cyc_B = _LazyUnpad(c2[lo], self.input_c_dim), _LazyUnpad(c2[hi], C)
+        if self.keep_tapes:            # stacked [first network's images; second network's images] -- see the docstring
+            self.tapes = {"G_first": t1, "G_second": t2, "D_fake": tDf, "D_real": tDr, "n": n}
         return self.gen_loss, self.disc_loss
 
     # ------------------------------------------------------------------ convenience
@@ -577,13 +629,18 @@ class sggan(object):
 
 
 class _PendingReduce:
-    """Handle of one gradient all-reduce: ``wait()`` orders the compute stream behind it (a host action, see _host)."""
+    """Handle of one network's gradient all-reduces (one per bucket): ``wait()`` orders the compute stream behind all of
+    them (a host action, see _host)."""
 
     def __init__(self, model):
-        self._model, self.work = model, None
+        self._model, self.works = model, []
 
     def wait(self):
-        self._model._host(lambda: self.work.wait())
+        def wait_all():
+            for w in self.works:
+                w.wait()
+            self.works.clear()
+        self._model._host(wait_all)
 
 
 class _LazyUnpad:

@@ -14,8 +14,6 @@ shape-agnostic, geometry is resolved per call.
 """
 from __future__ import annotations
 
-import os
-
 import math
 
 import numpy as np
@@ -195,14 +193,44 @@ def discriminator_param_specs(df_dim=64, in_c=3, segment_class=34):
     return L
 
 
+def plan_buckets(P, unit_names, n_buckets):
+    """Contiguous ranges of a network's flat gradient buffer, cut at layer boundaries into ``n_buckets`` groups of about equal
+    size (plus, when there is more than one, the small leading layers as a bucket of their own -- below):
+    [(first_unit_name, lo, hi)] in flat (= forward) order, covering [0, P.numel) exactly.  Backward visits the layers in
+    reverse, so a group's gradients are complete once the backward of its FIRST unit (weight gradient included) has been queued
+    -- the point at which the data-parallel step launches that bucket's all-reduce."""
+    starts = [P.index[n + "_w"][0] for n in unit_names]
+    assert starts == sorted(starts) and starts[0] == 0, "units must be given in flat-buffer order"
+    total = P.numel
+    n_buckets = max(1, min(int(n_buckets), len(unit_names)))
+    cuts = [0]
+    for k in range(1, n_buckets):
+        target = total * k / n_buckets
+        i = min(range(len(unit_names)), key=lambda j: abs(starts[j] - target))
+        if i > cuts[-1]:
+            cuts.append(i)
+    # the group that completes LAST (the first in flat order) has nothing of the backward pass left to hide behind: cut its
+    # small leading layers (the generator's stem, <= 5 % of the buffer) off as a bucket of their own, so that the exposed
+    # exchange is a latency-sized one and the bulk of the group travels under those layers' backward
+    if len(cuts) > 1 or n_buckets > 1:
+        first_end = cuts[1] if len(cuts) > 1 else len(unit_names)
+        small = [j for j in range(1, first_end) if starts[j] <= 0.05 * total]
+        if small:
+            cuts.insert(1, small[-1])
+    ends = cuts[1:] + [len(unit_names)]
+    return [(unit_names[a], starts[a], total if b == len(unit_names) else starts[b]) for a, b in zip(cuts, ends)]
+
+
 # ----------------------------------------------------------------------------- layer engine
-FUSE_CONV_IN_STATS = os.environ.get("SGG_FUSE_IN_STATS", "1") != "0"     # A/B switch for the conv -> norm statistics fusion
-# ... and for its backward counterpart (data-gradient epilogue -> norm-backward sums).  OFF by default: the epilogue has to read the
-# norm input tile (and the skip gradient) at the end of a grid that has nothing to overlap the burst with.  Measured at the bench
-# shape after the epilogue clean-up of round 2 (tools/bench_conv.py --ops dgrad_add,dgrad_stats,in_bwd,in_bwd_partial): 8 images
-# +6.6 us per data gradient against 12.9 us saved in the norm; 16 images (the paired cycle step's launch size) +23.4 against 22.7
-# -- nothing left.  Kept, parity-tested, as an opt-in; it has no paired form.
-FUSE_CONV_IN_BWD = os.environ.get("SGG_FUSE_IN_BWD", "0") != "0"
+# Defaults of two per-network switches (``sggan(fuse_in_stats=..., fuse_in_bwd=...)`` / ``net.fuse_in_stats`` / ``net.fuse_in_bwd``;
+# nothing here reads the environment).  fuse_in_stats: the conv epilogue emits the following instance norm's per-chunk sums.
+# fuse_in_bwd: its backward counterpart (data-gradient epilogue -> norm-backward sums) -- OFF: the epilogue has to read the norm
+# input tile (and the skip gradient) at the end of a grid that has nothing to overlap the burst with.  Measured at the bench shape
+# (tools/bench_conv.py --ops dgrad_add,dgrad_stats,in_bwd,in_bwd_partial): 8 images +6.6 us per data gradient against 12.9 us saved
+# in the norm; 16 images (the paired cycle step's launch size) +23.4 against 22.7 -- nothing left.  Kept, parity-tested, as an
+# opt-in of the one-network-at-a-time sequencing; it has no paired form.
+FUSE_CONV_IN_STATS = True
+FUSE_CONV_IN_BWD = False
 
 
 class _ConvUnit:
@@ -259,7 +287,7 @@ class _ConvUnit:
         g = self.geom(x)
         wf, wd = self.packed(x.dtype)
         fused_act = A.ACT_NONE if self.norm else self.act
-        if self.kind == "conv" and self.norm and g.stats_chunks and FUSE_CONV_IN_STATS:
+        if self.kind == "conv" and self.norm and g.stats_chunks and self.net.fuse_in_stats:
             # the conv's epilogue emits the norm's per-chunk sums: the norm skips its own pass over the tensor
             xc, part = K.conv_fwd_stats(g, x, wf, P.p(n + "_b"))
             y, stats = K.instnorm_fwd_partial(xc, part, P.p(n + "_g"), P.p(n + "_beta"), residual, self.net.eps, self.act, self.leak)
@@ -325,7 +353,7 @@ class _ConvUnit:
                 addend = addend.to(dxc.dtype)
             if next_norm is not None:
                 nu, nrec = next_norm
-                if (not out_f32 and FUSE_CONV_IN_STATS and FUSE_CONV_IN_BWD and g.bwd_stats_chunks and nu.norm
+                if (not out_f32 and self.net.fuse_in_stats and self.net.fuse_in_bwd and g.bwd_stats_chunks and nu.norm
                         and tuple(nrec[2].shape) == g.x_shape):
                     NP = nu.net.P
                     return K.conv_dgrad_stats(g, dxc, wd, addend, nrec[2], nrec[3], NP.p(nu.name + "_g"), NP.p(nu.name + "_beta"),
@@ -356,6 +384,7 @@ class _Net:
         # mixed precision (bf16 networks only): data gradients that feed an instance-norm backward are kept in f32 where the
         # kernel supports it (the residual chain) -- see sgg_conv2d_bwd_data_mixed in include/sggan.h
         self.mixed = False
+        self.fuse_in_stats, self.fuse_in_bwd = FUSE_CONV_IN_STATS, FUSE_CONV_IN_BWD
         self._pack_tables = {}
 
     def conv_units(self):
@@ -379,6 +408,13 @@ class _Net:
     def flush_wgrads(self):
         for u in self.conv_units():
             u.flush_wgrad()
+
+    def pending_wgrads(self):
+        return [u.name for u in self.conv_units() if u._pending is not None]
+
+    def bucket_plan(self, n_buckets):
+        """plan_buckets() over this network's layers."""
+        return plan_buckets(self.P, [u.name for u in self.conv_units()], n_buckets)
 
     def scratch_vec(self, n):
         if self._scratch is None or self._scratch.numel() < n:
@@ -441,22 +477,32 @@ class Generator(_Net):
             tape.append(r)
         return h, tape
 
-    def backward(self, tape, dy, want_dx=False, param_grads=True, gbuf=None):
+    def backward(self, tape, dy, want_dx=False, param_grads=True, gbuf=None, on_unit_done=None):
+        """on_unit_done(name): called after each layer's backward (its weight gradient included) has been queued -- the
+        data-parallel step hangs its per-bucket all-reduce launches on it (``bucket_plan``)."""
         nb = self.n_blocks
+        done = on_unit_done if on_unit_done is not None else (lambda name: None)
         d = dy
         for u, r in zip((self.out, self.d2, self.d1), (tape[5 + nb], tape[4 + nb], tape[3 + nb])):
             d = u.backward(r, d, True, param_grads, gbuf)
+            done(u.name)
         # residual blocks: each data gradient also makes the first pass of the norm backward that consumes it (the
         # norm of the conv before it in forward order), so that norm skips its statistics pass over the tensor
         part = None
         blocks, recs = list(reversed(self.blocks)), list(reversed(tape[3:3 + nb]))
         for k, ((ua, ub), (ra, rb)) in enumerate(zip(blocks, recs)):
             t, pa = ub.backward(rb, d, True, param_grads, gbuf, dy_partial=part, next_norm=(ua, ra))
+            done(ub.name)
             nxt = (blocks[k + 1][1], recs[k + 1][1]) if k + 1 < nb else (self.c3, tape[2])
             d, part = ua.backward(ra, t, True, param_grads, gbuf, addend=d, dy_partial=pa, next_norm=nxt)   # + skip gradient (fused)
+            done(ua.name)
         d = self.c3.backward(tape[2], d, True, param_grads, gbuf, dy_partial=part)
+        done("c3")
         d = self.c2.backward(tape[1], d, True, param_grads, gbuf)
-        return self.c1.backward(tape[0], d, want_dx, param_grads, gbuf)
+        done("c2")
+        d = self.c1.backward(tape[0], d, want_dx, param_grads, gbuf)
+        done("c1")
+        return d
 
     def __call__(self, x):
         """Drop-in for ``self.generator(self.real_A)`` (model.py:175): NHWC float32 in, NHWC float32 out."""
@@ -558,7 +604,7 @@ class _PairUnit:
         PA, PB = ua.net.P, ub.net.P
         fused_act = A.ACT_NONE if ua.norm else ua.act
         g2 = ua.geom(x) if ua.kind == "conv" else None     # geometry of the stacked batch
-        if ua.kind == "conv" and ua.norm and g.stats_chunks and FUSE_CONV_IN_STATS and g2.pair_ok:
+        if ua.kind == "conv" and ua.norm and g.stats_chunks and ua.net.fuse_in_stats and g2.pair_ok:
             # one launch for both networks (per-image weights): 512 blocks, the second round's halo loads run under the
             # first round's stores
             wfa, _ = ua.packed(x.dtype)
@@ -568,7 +614,7 @@ class _PairUnit:
                                                    residual, ua.net.eps, ua.act, ua.leak)
             return y, (g, x, xc, stats)
         xc = torch.empty((2 * n,) + tuple(g.y_shape[1:]), dtype=x.dtype, device=x.device)
-        if ua.kind == "conv" and ua.norm and g.stats_chunks and FUSE_CONV_IN_STATS:
+        if ua.kind == "conv" and ua.norm and g.stats_chunks and ua.net.fuse_in_stats:
             part = torch.empty((2 * n, g.stats_chunks, g.y_shape[3], 2), dtype=torch.float32, device=x.device)
             for u, sl in halves:
                 wf, _ = u.packed(x.dtype)
@@ -661,17 +707,26 @@ class GeneratorPair:
             tape.append(r)
         return h, tape
 
-    def backward(self, tape, dy, want_dx=False, param_grads=True):
+    def backward(self, tape, dy, want_dx=False, param_grads=True, on_unit_done=None):
+        """on_unit_done(name): as Generator.backward -- both networks of the pair finish a layer together."""
         nb = len(self.blocks)
+        done = on_unit_done if on_unit_done is not None else (lambda name: None)
         d = dy
         for u, r in zip(reversed(self.tail), (tape[5 + nb], tape[4 + nb], tape[3 + nb])):
             d = u.backward(r, d, True, param_grads)
+            done(u.ua.name)
         for (ua, ub), (ra, rb) in zip(reversed(self.blocks), reversed(tape[3:3 + nb])):
             t = ub.backward(rb, d, True, param_grads)
+            done(ub.ua.name)
             d = ua.backward(ra, t, True, param_grads, addend=d)      # + skip gradient (fused into the data-gradient epilogue)
+            done(ua.ua.name)
         d = self.head[2].backward(tape[2], d, True, param_grads)
+        done("c3")
         d = self.head[1].backward(tape[1], d, True, param_grads)
-        return self.head[0].backward(tape[0], d, want_dx, param_grads)
+        done("c2")
+        d = self.head[0].backward(tape[0], d, want_dx, param_grads)
+        done("c1")
+        return d
 
 
 class DiscriminatorPair:

@@ -55,13 +55,14 @@ def inverse_transform(images):
 
 
 def merge(images, size):
-    """utils.py:261-269: tile (B,h,w,3) images on a size[0] x size[1] grid."""
-    h, w = images.shape[1], images.shape[2]
-    img = np.zeros((h * size[0], w * size[1], 3))
-    for idx, image in enumerate(images):
-        i, j = idx % size[1], idx // size[1]
-        img[j * h:j * h + h, i * w:i * w + w, :] = image
-    return np.array(img).astype(np.uint8)
+    """utils.py:261-269: image k of a (B,h,w,3) batch goes to cell (k // size[1], k % size[1]) of a size[0] x size[1] grid;
+    cells without an image stay black.  One reshape/transpose of the padded batch instead of a paste loop."""
+    rows, cols = int(size[0]), int(size[1])
+    images = np.asarray(images)
+    b, h, w = images.shape[:3]
+    cells = np.zeros((rows * cols, h, w, 3), dtype=np.float64)
+    cells[:b] = images[:rows * cols]
+    return cells.reshape(rows, cols, h, w, 3).transpose(0, 2, 1, 3, 4).reshape(rows * h, cols * w, 3).astype(np.uint8)
 
 
 def get_img(image, size):

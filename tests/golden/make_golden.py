@@ -234,9 +234,74 @@ def make_oracle_d256():
     print("d256 step: gen_loss", r["gen_loss"], "disc_loss", r["disc_loss"])
 
 
+def bf16_mid_inputs(seed=29):
+    """Seeded parameters + inputs of the 'mid' case of oracle_bf16_emulated.npz: gf_dim = df_dim = 16, 3 residual blocks,
+    1x256x256 (D map 5x5: the generator receives D's gradient and every D gradient is non-zero)."""
+    rng = np.random.default_rng(seed)
+    f32 = lambda a: a.astype(np.float32)
+    PG = {k: f32(v) for k, v in O.init_params(O.generator_param_shapes(gf_dim=16, n_blocks=3), rng, perturb=0.1).items()}
+    PD = {k: f32(v) for k, v in O.init_params(O.discriminator_param_shapes(df_dim=16), rng, perturb=0.1).items()}
+    real = f32(rng.integers(0, 256, (1, 256, 256, 3)) / 255.0)
+    seg = f32(rng.integers(0, 256, (1, 256, 256, 3)) / 255.0)
+    mask = np.stack([O.one_hot(i, 34) for i in rng.integers(0, 34, (1, 5, 5))]).astype(np.float32)
+    return PG, PD, real, seg, mask
+
+
+def small_inputs():
+    z = np.load(os.path.join(HERE, "oracle_small.npz"))
+    PG = {k[3:]: z[k] for k in z.files if k.startswith("PG/")}
+    PD = {k[3:]: z[k] for k in z.files if k.startswith("PD/")}
+    real = z["real_A_u8"].astype(np.float32) / np.float32(255)
+    seg = z["seg_A_u8"].astype(np.float32) / np.float32(255)
+    mask = np.stack([O.one_hot(i, 34) for i in z["mask_idx"]]).astype(np.float32)
+    return PG, PD, real, seg, mask
+
+
+def make_bf16_emulated():
+    """oracle_bf16_emulated.npz -- the step-level oracle of the TIMED (bf16-storage) path: the PyTorch-CPU restatement of the
+    reference-mode step evaluated in float64 with every tensor the MI355X path stores rounded to bfloat16 exactly where it
+    stores one (oracle/torch_restatement.py bf16_storage: conv outputs, layer outputs, inputs, the GEMM's weight copy; values
+    on the way forward, gradients on the way back).  (The rounded 29-layer chain is sensitive: a value that crosses a rounding
+    boundary moves the values behind it by far more than f32 noise, which moves further ones -- by the generator's output
+    about a quarter of the pixels differ by one bf16 step between two correct evaluations, `fake_floor`.)  Two cases: 'small' (the oracle_small.npz inputs: gf = df = 8, 2 blocks,
+    2x128x128) and 'mid' (bf16_mid_inputs).  Per case: losses, the generator image, every parameter gradient, and
+    ``floor/<net>/<tensor>`` = 1 - cosine between this float64 evaluation and the SAME emulation evaluated in float32 -- two
+    correct implementations of one storage policy differ by that much, because f32-vs-f64 summation noise moves values across
+    bf16 rounding boundaries (most easily the small ones) and the rounded backward chain carries each flip on."""
+    import torch
+    from oracle import torch_restatement as T
+    out = {}
+    for case, (PG, PD, real, seg, mask), nb in (("small", small_inputs(), 2), ("mid", bf16_mid_inputs(), 3)):
+        res = {}
+        for tag, dtype in (("f64", torch.float64), ("f32", torch.float32)):
+            with T.bf16_storage():
+                res[tag] = T.RefStep(PG, PD, dtype, n_blocks=nb).step(real, seg, mask, apply=False)
+        plain = T.RefStep(PG, PD, torch.float64, n_blocks=nb).step(real, seg, mask, apply=False)
+        r = res["f64"]
+        out[f"{case}/gen_loss"], out[f"{case}/disc_loss"] = np.array(r["gen_loss"]), np.array(r["disc_loss"])
+        out[f"{case}/gen_loss_f32path"], out[f"{case}/disc_loss_f32path"] = np.array(plain["gen_loss"]), np.array(plain["disc_loss"])
+        out[f"{case}/fake_A"] = r["fake_A"].numpy().astype(np.float32)
+        fa, fb = r["fake_A"].numpy().astype(np.float64), res["f32"]["fake_A"].numpy().astype(np.float64)
+        d, step = np.abs(fa - fb), np.maximum(np.abs(fa), 2.0 ** -7) * 2.0 ** -7         # one bf16 step at that magnitude
+        out[f"{case}/fake_floor"] = np.array([d.mean(), d.max(), (d > 1.01 * step).mean()])   # same emulation, f32 vs f64
+        out[f"{case}/da_fake"], out[f"{case}/da_real"] = r["da_fake"].numpy(), r["da_real"].numpy()
+        cosd = lambda a, b: 1.0 - float((a.double() * b.double()).sum() / (a.double().norm() * b.double().norm() + 1e-300))
+        worst = 0.0
+        for net in ("gG", "gD"):
+            for k, g in r[net].items():
+                out[f"{case}/{net}/{k}"] = g.numpy().astype(np.float32)
+                fl = cosd(g, res["f32"][net][k]) if float(g.double().norm()) > 0 else 0.0
+                out[f"{case}/floor/{net}/{k}"] = np.array(fl)
+                out[f"{case}/f32path_dist/{net}/{k}"] = np.array(cosd(g, plain[net][k]) if float(g.double().norm()) > 0 else 0.0)
+                worst = max(worst, fl)
+        print(case, "gen_loss", r["gen_loss"], "(f32 path %.6f)" % plain["gen_loss"], "disc_loss", r["disc_loss"],
+              "worst floor 1-cos %.2e" % worst)
+    np.savez_compressed(os.path.join(HERE, "oracle_bf16_emulated.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["segclass", "small", "full", "zoom", "d256"]
+    which = sys.argv[1:] or ["segclass", "small", "full", "zoom", "d256", "bf16emu"]
     for name, fn in (("segclass", make_segclass), ("small", make_oracle_small), ("full", make_oracle_full),
-                     ("zoom", make_mask_zoom), ("d256", make_oracle_d256)):
+                     ("zoom", make_mask_zoom), ("d256", make_oracle_d256), ("bf16emu", make_bf16_emulated)):
         if name in which:
             fn()

@@ -79,3 +79,46 @@ def test_product_path_has_no_cpu_fallback():
     for f in os.listdir(pkg):
         if f.endswith(".py"):
             assert "oracle" not in open(os.path.join(pkg, f)).read().replace("CPU oracle under oracle/ is test infrastructure", ""), f
+
+
+def test_gradient_bucket_plan_covers_the_buffer_in_backward_order():
+    """module.plan_buckets (the data-parallel step's layer-group buckets): contiguous, disjoint, covering the
+    whole flat gradient buffer, cut at layer boundaries, the stem as a small bucket of its own."""
+    from sggan_amd.module import ParamStore, generator_param_specs, plan_buckets
+    P = ParamStore(generator_param_specs(), "cpu")
+    names = ["c1", "c2", "c3"] + [f"r{i}{x}" for i in range(1, 10) for x in "ab"] + ["d1", "d2", "out"]
+    assert plan_buckets(P, names, 1) == [("c1", 0, P.numel)]
+    for n in (2, 3, 4, 6, 50):
+        plan = plan_buckets(P, names, n)
+        assert plan[0][:2] == ("c1", 0) and plan[-1][2] == P.numel and len(plan) <= len(names)
+        assert all(a[2] == b[1] and a[1] < a[2] for a, b in zip(plan, plan[1:] + [(None, P.numel, None)]))
+        assert all(lo == P.index[first + "_w"][0] for first, lo, _ in plan)
+        if n <= 6:
+            assert plan[1][0] == "r1a" and plan[0][2] - plan[0][1] < 0.05 * P.numel        # stem: c1..c3, 3 % of the buffer
+            sizes = [hi - lo for _, lo, hi in plan[1:]]
+            assert max(sizes) < 1.35 * min(sizes)
+
+
+def test_merge_tiles_like_the_reference_loop():
+    """utils.merge (utils.py:261-269) against the paste loop it replaces, incl. a partly filled grid."""
+    from sggan_amd.utils import merge
+    rng = np.random.default_rng(0)
+    for b, size in ((6, (2, 3)), (4, (2, 3)), (1, (1, 1)), (8, (4, 2))):
+        imgs = rng.integers(0, 256, (b, 5, 7, 3)).astype(np.uint8)
+        h, w = 5, 7
+        exp = np.zeros((h * size[0], w * size[1], 3))
+        for idx, im in enumerate(imgs):
+            i, j = idx % size[1], idx // size[1]
+            exp[j * h:j * h + h, i * w:i * w + w, :] = im
+        assert np.array_equal(merge(imgs, size), exp.astype(np.uint8))
+
+
+def test_package_reads_no_environment():
+    """neither the library nor the Python side of the drop-in takes configuration from the environment --
+    switches are constructor arguments (default_args), the library path is explicit (_abi.use_library).  build.py (the
+    build script, HIPCC override) is not part of the runtime path."""
+    pkg = os.path.join(ROOT, "sg-gan-tf2_amd")
+    for f in sorted(os.listdir(pkg)):
+        if f.endswith(".py") and f != "build.py":
+            src = open(os.path.join(pkg, f)).read()
+            assert "os.environ" not in src and "getenv" not in src, f

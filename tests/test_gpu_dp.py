@@ -10,6 +10,7 @@
 import os
 import socket
 import sys
+import warnings
 
 import numpy as np
 import pytest
@@ -51,11 +52,27 @@ def test_dp_world1_rccl_is_bit_identical_to_plain_step(cycle):
             if dp:
                 m.enable_data_parallel()
             _set(m, a, b)
-            for _ in range(2):
-                m.train_step()
-            if dp and graph:      # the collectives sit BETWEEN graph segments: one all-reduce + one wait per network
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                for _ in range(2):
+                    m.train_step()
+            assert not [w for w in caught if "Graph is empty" in str(w.message)], "an empty HIP-graph segment was recorded"
+            if dp and graph:
+                # the collectives sit BETWEEN graph segments.  Host actions: one launch per discriminator bucket, one per
+                # generator layer-group bucket (both generators of the paired cycle step share it), one wait per network;
+                # actions with no launch between them share a cut, so graphs = cuts + 1 and the program starts and ends
+                # with a graph
                 kinds = [k for k, _ in m._program.items]
-                assert kinds.count("host") == 2 * len(m.networks()) and kinds.count("graph") == kinds.count("host") + 1
+                plan = m.generator.bucket_plan(m.g_buckets)
+                assert len(plan) >= 3 and plan[0][1] == 0 and plan[-1][2] == m.generator.P.numel
+                assert all(a_[2] == b_[1] for a_, b_ in zip(plan, plan[1:]))
+                n_d = len(m.networks()) // 2
+                assert kinds.count("host") == n_d + len(plan) + len(m.networks())
+                runs = sum(1 for i, k in enumerate(kinds) if k == "host" and (i == 0 or kinds[i - 1] != "host"))
+                assert kinds[0] == "graph" and kinds[-1] == "graph" and kinds.count("graph") == runs + 1
+                assert "graphgraph" not in "".join(kinds)
+                if cycle:                                 # D_A's and D_B's launches are adjacent: they share one cut
+                    assert runs < kinds.count("host")
             states.append([t.clone() for n in m.networks() for t in (n.P.flat, n.P.grad, n.P.m, n.P.v)] + [m._loss.clone()])
         for other in states[1:]:
             for x, y in zip(states[0], other):

@@ -84,3 +84,52 @@ def test_graph_inputs_in_place_and_reshape(sg):
     m.real_A, m.seg_A, m.mask_A = _rand_inputs(2, 256, 256, m.discriminator, 3)
     m.train_step()
     assert m._program is not prog
+
+
+def test_eager_inference_between_graph_replays_sees_the_updated_weights(sg):
+    """A replayed step runs Adam on the device; the host-side re-pack trigger (ParamStore.version) must move with it, or an
+    eager ``generator(x)`` after a replay (test_during_train at every epoch end, model.py:263) would convolve with packed
+    weights that are one or more steps old.  graph steps -> eager generator -> graph steps -> eager generator, against an
+    all-eager model: bitwise the same images."""
+    def run(graph):
+        m = sg.sggan(sg.default_args(ngf=8, ndf=8, n_blocks=1, dtype="bf16", graph=graph))
+        x = torch.rand((1, 256, 256, 3), generator=torch.Generator().manual_seed(9)).cuda()
+        outs = [m.generator(x).clone()]
+        for rnd in range(3):
+            for step in range(2):
+                m.real_A, m.seg_A, m.mask_A = _rand_inputs(1, 256, 256, m.discriminator, 70 + 2 * rnd + step)
+                m.train_step()
+            outs.append(m.generator(x).clone())
+        m.enable_graph(False)                              # ... and an eager train step after replays
+        m.real_A, m.seg_A, m.mask_A = _rand_inputs(1, 256, 256, m.discriminator, 99)
+        m.train_step()
+        outs.append(m.generator(x).clone())
+        return outs
+    eager, graph = run(False), run(True)
+    assert not torch.equal(eager[0], eager[1]) and not torch.equal(eager[1], eager[2])      # the weights do move
+    for i, (a, b) in enumerate(zip(eager, graph)):
+        assert torch.equal(a, b), i
+
+
+def test_recorded_program_keeps_its_workspace_alive(sg):
+    """The scratch workspace is allocated outside the capture pool and its address is baked into the recorded launches: a
+    later, larger request must not free it under the program (it would be handed to another tensor and silently overwritten
+    by every replay).  Record a step, force the workspace to grow, allocate over the freed pool, replay: same result as a
+    model that never saw the growth."""
+    from sggan_amd import kernels as K
+    def run(disturb):
+        m = sg.sggan(sg.default_args(ngf=8, ndf=8, n_blocks=1, dtype="f32", graph=True, cycle=True))
+        m.real_A, m.seg_A, m.mask_A = _rand_inputs(1, 256, 256, m.discriminator, 5)
+        m.real_B, m.seg_B, m.mask_B = _rand_inputs(1, 256, 256, m.discriminator, 6)
+        m.train_step()
+        if disturb:
+            old = K.workspace(1, m.device)
+            assert any(t is old for t in m._program.keep)
+            big = K.workspace(old.numel() * 2 + (64 << 20), m.device)          # replaces the shared buffer
+            assert big is not old
+            del old
+            junk = [torch.full((1 << 20,), float("nan"), device=m.device) for _ in range(64)]   # would land in the freed block
+        m.train_step()
+        return [n.P.flat.clone() for n in m.networks()] + [m._loss.clone()]
+    for a, b in zip(run(False), run(True)):
+        assert torch.equal(a, b)

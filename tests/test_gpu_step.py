@@ -78,6 +78,8 @@ def test_train_step_small_f32_matches_oracle(sg):
 
 
 def test_train_step_small_bf16_close_to_oracle(sg):
+    """bf16 path vs the FLOAT64 oracle of the f32 function (the distance is bf16 storage of the forward activations, see
+    tests/test_bf16_fidelity_cpu.py; the tight step-level statement about the bf16 path is the next test)."""
     m, z = small_model(sg, "bf16")
     m.train_step()
     gl, dl = m.losses()
@@ -85,14 +87,61 @@ def test_train_step_small_bf16_close_to_oracle(sg):
     assert abs(dl - float(z["disc_loss"])) < 1e-2 * abs(float(z["disc_loss"]))
     d = np.abs(m.fake_A.numpy() - z["fake_A"])                                        # tanh output in [-1,1]
     assert d.max() < 0.1 and d.mean() < 1e-2, (d.max(), d.mean())
-    # gradients: bf16 storage of every activation/gradient tensor; on these 8-channel toy networks the rounding
-    # noise grows towards the input (measured cos 0.93-0.99 early, >0.999 late; f32 path is exact to 2e-4 above)
-    gG = m.generator.P.export(m.generator.P.grad)
-    cos = lambda v, e: float((v.astype(np.float64) * e).sum() / (np.linalg.norm(v) * np.linalg.norm(e) + 1e-30))
-    for k, lo in (("c1_w", 0.9), ("r1a_w", 0.9), ("r2b_w", 0.95), ("d1_w", 0.98), ("d2_w", 0.999), ("out_w", 0.9999)):
-        assert cos(gG[k], z["gG/" + k]) > lo, (k, cos(gG[k], z["gG/" + k]))
-    gD = m.discriminator.P.export(m.discriminator.P.grad)
-    assert cos(gD["h4_w"], z["gD/h4_w"]) > 0.999
+
+
+@pytest.mark.parametrize("case", ["small", "mid"])
+def test_bf16_step_matches_the_bf16_storage_emulating_oracle(sg, case):
+    """The TIMED path's step-level oracle (tests/golden/oracle_bf16_emulated.npz, make_golden.make_bf16_emulated): the
+    PyTorch-CPU restatement in float64 with every tensor the HIP path stores rounded to bfloat16 where it stores one (values
+    forward, gradients backward, the GEMM's weight copy).  Against THAT oracle the bf16 step has no modelling distance left --
+    what remains is f32-vs-f64 summation noise moving values across bf16 rounding boundaries, which the rounded backward chain
+    carries on; the fixture records how far the same emulation evaluated in float32 lands from the float64 one per tensor
+    (`floor`, 1 - cosine; `fake_floor` for the image).  Bars: losses within 1e-3 (1e-5 measured -- the f32 function is 1e-3
+    away), the image within 1.5 x its floor (mean |err|, share of pixels off by more than one bf16 step), and every
+    parameter-gradient tensor within 4 x floor + 2e-4 of the oracle in 1 - cosine -- i.e. as close as another correct
+    implementation of the same storage policy.  (VERDICT r02 asked for cosine >= 0.999 on every tensor: the floor column shows
+    no two correct bf16-storage evaluations of these networks agree that closely on the early layers; the tensors that can,
+    do -- the count is printed.)"""
+    from tests.golden.make_golden import bf16_mid_inputs, small_inputs
+    z = np.load(os.path.join(G, "oracle_bf16_emulated.npz"))
+    if case == "small":
+        PG, PD, real, seg, mask = small_inputs()
+        m = sg.sggan(sg.default_args(ngf=8, ndf=8, n_blocks=2, dtype="bf16"))
+    else:
+        PG, PD, real, seg, mask = bf16_mid_inputs()
+        m = sg.sggan(sg.default_args(ngf=16, ndf=16, n_blocks=3, dtype="bf16"))
+    m.generator.P.load(PG); m.discriminator.P.load(PD)
+    m.real_A, m.seg_A, m.mask_A = real, seg, mask
+    m.train_step()
+    gl, dl = m.losses()
+    e_gl, e_dl = float(z[f"{case}/gen_loss"]), float(z[f"{case}/disc_loss"])
+    print(f"[{case}] gen_loss {gl:.6f} vs emulated {e_gl:.6f} (f32 function {float(z[case + '/gen_loss_f32path']):.6f}); "
+          f"disc_loss {dl:.6f} vs {e_dl:.6f} ({float(z[case + '/disc_loss_f32path']):.6f})")
+    assert abs(gl - e_gl) < 1e-3 * abs(e_gl) and abs(dl - e_dl) < 1e-3 * abs(e_dl)
+    d = np.abs(m.fake_A.numpy().astype(np.float64) - z[f"{case}/fake_A"])
+    step = np.maximum(np.abs(z[f"{case}/fake_A"]), 2.0 ** -7) * 2.0 ** -7            # one bf16 step at that magnitude (8 significant bits)
+    print(f"[{case}] image: mean |err| {d.mean():.2e}, max {d.max():.2e}, pixels off by more than one bf16 step: {(d > 1.01 * step).mean():.2e}")
+    f_mean, f_max, f_frac = (float(v) for v in z[f"{case}/fake_floor"])
+    print(f"[{case}] image floor (the emulation in f32 vs f64): mean {f_mean:.2e}, max {f_max:.2e}, beyond one step {f_frac:.2e}")
+    assert d.mean() < 1.5 * f_mean + 1e-4 and (d > 1.01 * step).mean() < 1.5 * f_frac + 1e-2 and d.max() < 2.0 * f_max
+    cosd = lambda v, e: 1.0 - float((v.astype(np.float64) * e).sum() / (np.linalg.norm(v.astype(np.float64)) * np.linalg.norm(e.astype(np.float64)) + 1e-300))
+    table, bad = [], []
+    for net, P in (("gG", m.generator.P), ("gD", m.discriminator.P)):
+        got = P.export(P.grad)
+        norms = {k: float(np.linalg.norm(z[f"{case}/{net}/{k}"].astype(np.float64))) for k in got}
+        top = max(norms.values())
+        for k, v in got.items():
+            if (k.endswith("_b") and k not in ("out_b", "h0_b", "h4_b")) or norms[k] < 1e-6 * top:
+                continue                         # bias in front of an instance norm / degenerate tensors (D at 128x128): no signal
+            dist, floor = cosd(v, z[f"{case}/{net}/{k}"]), float(z[f"{case}/floor/{net}/{k}"])
+            table.append((net, k, dist, floor, float(z[f"{case}/f32path_dist/{net}/{k}"])))
+            if dist > 4.0 * floor + 2e-4:
+                bad.append(table[-1])
+    worst = sorted(table, key=lambda t: -t[2])[:6]
+    print(f"[{case}] 1 - cos(HIP bf16, emulated oracle) | floor (emulation f32 vs f64) | 1 - cos(f32 function, emulated): worst tensors",
+          [(n, k, "%.1e" % a, "%.1e" % b, "%.1e" % c) for n, k, a, b, c in worst])
+    print(f"[{case}] tensors with cosine >= 0.999: {sum(1 for t in table if t[2] <= 1e-3)} of {len(table)}")
+    assert len(table) > 20 and not bad, bad
 
 
 def test_dropin_callables_and_autograd(sg):
@@ -141,15 +190,25 @@ def test_full_size_step_f32_matches_oracle_checksums(sg):
             assert abs(got[k] - e) < 2e-3 * max(e, 1e-8), (k, got[k], e)      # f32 vs f64 through 50+ layers
 
 
+def _l2(got, exp):
+    got, exp = np.asarray(got, np.float64), np.asarray(exp, np.float64)
+    return float(np.sqrt(((got - exp) ** 2).sum()) / max(np.sqrt((exp ** 2).sum()), 1e-300))
+
+
 def test_full_width_discriminator_backward_f32_matches_oracle_at_256(sg):
     """Reference-mode step at 1x256x256 with the FULL-WIDTH discriminator (df_dim 64: 512-channel tail, split-K layers,
-    stride-2 VALID layers; D map 5x5 so none of D's gradients degenerates to zero as they do at 128x128) against the
-    float64 oracle fixture tests/golden/oracle_d256.npz: every D gradient tensor by norm, 4 random-sign projections and
-    a strided sample of 4096 entries; the same for the post-Adam D parameters; G's gradients element-wise."""
-    from tests.golden.make_golden import SIGNS, d256_inputs, tensor_digest
+    stride-2 VALID layers; D map 5x5 so none of D's gradients degenerates to zero as they do at 128x128) and the reference's
+    LeakyReLU slope 0.3.  Forward (losses, image, logits) against the committed float64 fixture tests/golden/oracle_d256.npz;
+    EVERY gradient tensor of D (8.79 M parameters) and G, and the post-Adam parameters, against the live float64 oracle
+    evaluated kink-aware (oracle.KinkPolicy): the ~5 M ReLU / LeakyReLU decisions are the oracle's own except for the elements
+    whose pre-activation lies within 1e-4 of zero -- undecidable at float32 precision (round 2's fixture test needed 3e-2
+    because of ONE such element) -- where it follows the branch the kernels took; a disagreement outside that band fails
+    the test.  Bars: 2e-4 relative L2 and 2e-4 of the largest entry on every tensor (measured: 1.4e-5 worst)."""
+    from tests.golden.make_golden import d256_inputs
+    from tests.kink_helpers import discriminator_branches, generator_branches
     z = np.load(os.path.join(G, "oracle_d256.npz"))
     PG, PD, real, seg, mask = d256_inputs(int(z["seed"]))
-    m = sg.sggan(sg.default_args(ngf=8, ndf=64, n_blocks=2, dtype="f32"))
+    m = sg.sggan(sg.default_args(ngf=8, ndf=64, n_blocks=2, dtype="f32", keep_tapes=True))
     m.generator.P.load(PG); m.discriminator.P.load(PD)
     assert m.discriminator.P.n_real() == 8_791_970
     m.real_A, m.seg_A, m.mask_A = real, seg, mask
@@ -158,48 +217,48 @@ def test_full_width_discriminator_backward_f32_matches_oracle_at_256(sg):
     assert abs(gl - float(z["gen_loss"])) < 1e-5 * abs(float(z["gen_loss"])) and abs(dl - float(z["disc_loss"])) < 1e-5 * abs(float(z["disc_loss"]))
     assert rel(m.fake_A.numpy(), z["fake_A"]) < 1e-4
     assert rel(m.da_real.detach().cpu().numpy(), z["da_real"]) < 1e-4 and rel(m.da_fake.detach().cpu().numpy(), z["da_fake"]) < 1e-4
+    # the kernels' branch decisions, in the oracle's evaluation order: G, D(seg), D(fake)   (oracle.train_step)
+    t = m.tapes
+    branches = (generator_branches(m.generator, t["G"]) + discriminator_branches(m.discriminator, t["D_real"])
+                + discriminator_branches(m.discriminator, t["D_fake"]))
+    pol = O.KinkPolicy(1e-4, branches)
+    O.KINKS = pol
+    try:
+        r = O.train_step(PG, PD, real, seg, mask, n_blocks=2)
+    finally:
+        O.KINKS = None
+    print(f"kink-aware oracle: {pol.calls} activation layers, {pol.elements} elements, {pol.ambiguous} within 1e-4 of the kink, "
+          f"{pol.overridden} of those taken on the other side by the kernels, {pol.disagree_outside} disagreements outside the band")
+    assert pol.calls == len(branches) and pol.disagree_outside == 0 and 0 < pol.ambiguous < 1e-3 * pol.elements
+    assert abs(gl - r["gen_loss"]) < 1e-5 * abs(r["gen_loss"]) and abs(dl - r["disc_loss"]) < 1e-5 * abs(r["disc_loss"])
     worst = {}
-    for label, got_all, skip in (("gD", m.discriminator.P.export(m.discriminator.P.grad), ("h0_b", "h4_b")),
-                                 ("newPD", m.discriminator.P.export(), ("h0_b", "h4_b"))):
+    for label, got_all, exp_all, skip in (("gD", m.discriminator.P.export(m.discriminator.P.grad), r["gD"], ("h0_b", "h4_b")),
+                                          ("gG", m.generator.P.export(m.generator.P.grad), r["gG"], ("out_b",))):
         for k, v in got_all.items():
+            e = exp_all[k]
             if k.endswith("_b") and k not in skip:              # bias in front of an InstanceNorm: exactly 0 here, ~1e-16 in the oracle
-                if label == "gD":
-                    assert np.abs(v).max() == 0.0 and z["gD_digest/" + k][0] < 1e-9
+                assert np.abs(v).max() == 0.0 and np.abs(e).max() < 1e-9
                 continue
-            dg, smp = tensor_digest(v)
-            e_dg, e_smp = z[f"{label}_digest/{k}"], z[f"{label}_sample/{k}"]
-            norm = e_dg[0]
-            assert norm > 1e-3, (label, k, "degenerate expected tensor")       # the point of this fixture
-            if label == "gD":
-                # Element-wise the f32 path is within ~1e-6 of float64 EXCEPT behind
-                # LeakyReLU kinks: a pre-activation within f32 rounding of zero (a handful of the ~5 M activations of
-                # the two D passes) takes slope 1 on one side and 0.3 on the other, and that one element's difference
-                # spreads over every gradient below it (tools/diag_d_f32.py shows the single flipped element; the
-                # kink-free variant of this test, below, holds 2e-5 on every tensor).  Measured with the reference slope:
-                # 1e-3 ... 1.4e-2 of a tensor's norm on single projections / entries, depending on which elements flip.
-                # Hence 3e-2 here (norm: 5e-3) -- or twice what an independent f32 implementation (PyTorch-CPU,
-                # f32_floor) is off by, where that is more: h0's weight gradient sums a near-zero-mean field against an
-                # all-positive image (cancels to ~1e-3 of its terms).
-                tol = max(3e-2, 2.0 * float(z["f32_floor/" + k]))
-                assert abs(dg[0] - norm) / norm < max(5e-3, 2.0 * float(z["f32_floor/" + k])), (label, k, dg[0], norm)
-                errs = [abs(dg[0] - norm) / norm] + [abs(dg[1 + j] - e_dg[1 + j]) / norm for j in range(SIGNS)]
-                errs.append(np.abs(smp.astype(np.float64) - e_smp).max() / max(np.abs(e_smp).max(), 1e-30))
-                worst[k] = (max(errs), tol)
-            else:                                                   # parameters move by ~lr = 1e-3 per step
-                # Adam's first step is -lr*g/(|g|+eps): entries whose gradient is at rounding-noise level may flip sign
-                ge = z["gD_sample/" + k].astype(np.float64)          # same strided positions as the parameter sample
-                sig = np.abs(ge) > 1e-2 * np.abs(ge).max()          # (gradient noise here is ~1e-3 of the tensor: kink flips)
-                assert sig.mean() > 0.5 and np.abs(smp.astype(np.float64) - e_smp)[sig].max() < 2e-5, (label, k)
-    print("full-width D backward, worst relative error per tensor (error, tolerance):",
-          {k: (float("%.2e" % e), float("%.1e" % t)) for k, (e, t) in worst.items()})
-    assert all(e < t for e, t in worst.values()), {k: v for k, v in worst.items() if v[0] >= v[1]}
-    gG = m.generator.P.export(m.generator.P.grad)
-    for k, v in gG.items():
-        e = z["gG/" + k]
-        if k.endswith("_b") and k != "out_b":
+            assert np.sqrt((e ** 2).sum()) > 1e-3 or label == "gG", (label, k, "degenerate expected tensor")
+            if (label, k) in (("gD", "h0_w"), ("gD", "h0_b")):
+                continue
+            worst[(label, k)] = (_l2(v, e), rel(v, e))
+    print("full-width D step, kink-aware: worst tensors (relative L2, worst entry / largest entry):",
+          [(k, "%.1e" % a, "%.1e" % b) for k, (a, b) in sorted(worst.items(), key=lambda kv: -kv[1][0])[:5]])
+    assert all(a < 2e-4 and b < 2e-4 for a, b in worst.values()), {k: v for k, v in worst.items() if max(v) >= 2e-4}
+    gD = m.discriminator.P.export(m.discriminator.P.grad)
+    for k, v in m.discriminator.P.export().items():             # post-Adam parameters: lr = 1e-3 steps
+        if k.endswith("_b") and k not in ("h0_b", "h4_b"):
             continue
-        # G's gradient comes through D's data path (the same LeakyReLU kink flips as above) and G's own ReLUs
-        assert np.abs(e).max() > 0 and rel(v, e) < 1e-2, ("gG", k, rel(v, e))
+        ge = r["gD"][k]
+        sig = np.abs(ge) > 1e-3 * np.abs(ge).max()               # Adam's first step is -lr*g/(|g|+eps): rounding-level entries may flip
+        assert sig.mean() > 0.05 and np.abs(v - r["PD"][k])[sig].max() < 2e-5, ("newPD", k, float(sig.mean()))
+    # h0 (3 -> 64 on an all-positive image): its weight / bias gradient sums a near-zero-mean field against positive values and
+    # cancels to ~1e-3 of its terms -- PyTorch-CPU f32 is 6e-3 / 1.3e-2 of the tensor norm away from float64 here (f32_floor in
+    # the fixture).  The kernels accumulate these in f64 on the parity path (norm.hip / colsum) and hold the common bar too.
+    for k in ("h0_w", "h0_b"):
+        print(f"h0 {k}: relative L2 {_l2(gD[k], r['gD'][k]):.1e} (PyTorch-CPU f32: {float(z['f32_floor/' + k]):.1e})")
+        assert _l2(gD[k], r["gD"][k]) < 2e-4 and rel(gD[k], r["gD"][k]) < 2e-4, k
 
 
 def test_full_width_discriminator_backward_kink_free_f32_is_tight(sg):
@@ -316,8 +375,6 @@ def test_fused_paths_match_unfused_at_bench_width(sg):
     epilogue (opt-in), paired weight gradients -- against the same step with all of them off: same kernels otherwise, so
     losses and every parameter gradient agree to f32-summation-order noise.  (256x512 is the smallest input whose
     residual maps, 64x128, take the halo-resident 3x3 kernels.)"""
-    import sggan_amd.module as M
-
     from sggan_amd import kernels as K
     calls = {"fwd": 0, "bwd": 0, "pair": 0}
     orig = (K.conv_fwd_stats, K.conv_dgrad_stats, K.conv_wgrad_pair)
@@ -329,13 +386,12 @@ def test_fused_paths_match_unfused_at_bench_width(sg):
         return w
 
     def grads(fuse_fwd, fuse_bwd, pair):
-        old = (M.FUSE_CONV_IN_STATS, M.FUSE_CONV_IN_BWD)
-        M.FUSE_CONV_IN_STATS, M.FUSE_CONV_IN_BWD = fuse_fwd, fuse_bwd
         K.conv_fwd_stats, K.conv_dgrad_stats, K.conv_wgrad_pair = (counted(n, f) for n, f in zip(("fwd", "bwd", "pair"), orig))
         for k in calls:
             calls[k] = 0
         try:
-            m = sg.sggan(sg.default_args(dtype="bf16", cycle=True, n_blocks=2, pair_wgrads=pair, paired=False))   # the one-network engine's paths
+            m = sg.sggan(sg.default_args(dtype="bf16", cycle=True, n_blocks=2, pair_wgrads=pair, paired=False,   # the one-network engine's paths
+                                         fuse_in_stats=fuse_fwd, fuse_in_bwd=fuse_bwd))
             a = _rand_inputs(1, 256, 512, m.discriminator, 5)
             b = _rand_inputs(1, 256, 512, m.discriminator, 6)
             m.real_A, m.seg_A, m.mask_A = a
@@ -347,7 +403,6 @@ def test_fused_paths_match_unfused_at_bench_width(sg):
             assert calls["pair"] == (8 if pair else 0)
             return gl, dl, [n.P.grad.clone() for n in m.networks()]
         finally:
-            M.FUSE_CONV_IN_STATS, M.FUSE_CONV_IN_BWD = old
             K.conv_fwd_stats, K.conv_dgrad_stats, K.conv_wgrad_pair = orig
 
     ref = grads(False, False, False)
@@ -362,7 +417,10 @@ def test_fused_paths_match_unfused_at_bench_width(sg):
 
 
 def test_cycle_step_small_f32_matches_oracle(sg):
-    """2G+2D cycle-mode step (deviation D5) vs the oracle's cycle_step on reduced networks, LSGAN and SCE criteria."""
+    """2G+2D cycle-mode step (deviation D5) vs the oracle's cycle_step on reduced networks, LSGAN and SCE criteria; the oracle is
+    evaluated kink-aware (see test_full_width_discriminator_backward_f32_matches_oracle_at_256), so every gradient tensor of
+    the four networks is held to 2e-4 (round 2: 5e-3 / 3e-2)."""
+    from tests.kink_helpers import discriminator_branches, generator_branches
     rng = np.random.default_rng(23)
     f32 = lambda a: a.astype(np.float32).astype(np.float64)
     gs = O.generator_param_shapes(gf_dim=8, n_blocks=1); ds = O.discriminator_param_shapes(df_dim=8)
@@ -375,15 +433,33 @@ def test_cycle_step_small_f32_matches_oracle(sg):
         seg_A, seg_B = blocks(), blocks()
         mk = lambda: np.stack([O.one_hot(i, 34) for i in rng.integers(0, 34, (N, 5, 5))]).astype(np.float64)
         mask_A, mask_B = mk(), mk()
-        r = O.cycle_step(P["Gab"], P["Gba"], P["Da"], P["Db"], real_A, real_B, seg_A, seg_B, mask_A, mask_B,
-                         use_lsgan=use_lsgan, n_blocks=1)
-        m = sg.sggan(sg.default_args(ngf=8, ndf=8, n_blocks=1, dtype="f32", cycle=True, use_lsgan=use_lsgan))
+        m = sg.sggan(sg.default_args(ngf=8, ndf=8, n_blocks=1, dtype="f32", cycle=True, use_lsgan=use_lsgan, keep_tapes=True))
         nets = {"Gab": m.generator, "Gba": m.generator_BA, "Da": m.discriminator, "Db": m.discriminator_B}
         for n, net in nets.items():
             net.P.load(P[n])
         m.real_A, m.real_B, m.seg_A, m.seg_B, m.mask_A, m.mask_B = real_A, real_B, seg_A, seg_B, mask_A, mask_B
         m.train_step()
         gl, dl = m.losses()
+        # kink-aware float64 oracle (oracle.KinkPolicy): ReLU / LeakyReLU elements within 1e-4 of zero follow the kernels' branch.
+        # The kernels' decisions in oracle.cycle_step's evaluation order; the paired step stacks [first net; second net] images:
+        # G_first = (G_ab(real_A); G_ba(real_B)), G_second = (G_ba(fake_B); G_ab(fake_A)), D_fake = (D_b(fake_B); D_a(fake_A)),
+        # D_real = (D_a(real_A); D_b(real_B))
+        t, lo, hi = m.tapes, slice(0, N), slice(N, 2 * N)
+        Gab_, Gba_, Da_, Db_ = m.generator, m.generator_BA, m.discriminator, m.discriminator_B
+        branches = (generator_branches(Gab_, t["G_first"], lo) + generator_branches(Gba_, t["G_second"], lo)
+                    + generator_branches(Gba_, t["G_first"], hi) + generator_branches(Gab_, t["G_second"], hi)
+                    + discriminator_branches(Db_, t["D_fake"], lo) + discriminator_branches(Da_, t["D_fake"], hi)
+                    + discriminator_branches(Da_, t["D_real"], lo) + discriminator_branches(Db_, t["D_real"], hi))
+        pol = O.KinkPolicy(1e-4, branches)
+        O.KINKS = pol
+        try:
+            r = O.cycle_step(P["Gab"], P["Gba"], P["Da"], P["Db"], real_A, real_B, seg_A, seg_B, mask_A, mask_B,
+                             use_lsgan=use_lsgan, n_blocks=1)
+        finally:
+            O.KINKS = None
+        print(f"kink-aware oracle: {pol.elements} activations, {pol.ambiguous} within 1e-4 of a kink, {pol.overridden} taken on the other "
+              f"side by the kernels, {pol.disagree_outside} disagreements outside the band")
+        assert pol.calls == len(branches) and pol.disagree_outside == 0
         assert abs(gl - r["g_loss"]) < 2e-5 * abs(r["g_loss"]) and abs(dl - r["d_loss"]) < 2e-5 * abs(r["d_loss"]), (gl, r["g_loss"], dl, r["d_loss"])
         assert rel(m.fake_B.numpy(), r["fake_B"]) < 1e-4 and rel(m.cyc_A.numpy(), r["cyc_A"]) < 2e-4
         worst = {}
@@ -392,13 +468,12 @@ def test_cycle_step_small_f32_matches_oracle(sg):
             for k, e in r["grads"][n].items():
                 if np.abs(e).max() < 1e-9:
                     continue
-                # sign() in the L1 / gradient-sensitive terms and the ReLU / LeakyReLU kinks make the gradient piecewise
-                # constant in the activations: f32-vs-f64 differences flip a few near-zero elements, each of which
-                # moves single entries of the gradients below it -- so the bound is on the tensor (relative L2),
-                # with a looser one on the worst single entry
+                # what is left after the activation kinks are pinned: sign() in the L1 / gradient-sensitive terms (an image
+                # difference within f32 rounding of zero flips a +-lambda/N entry of the image gradient -- a handful of the
+                # 400 k pixels) and f32 accumulation
                 l2 = float(np.sqrt(((got[k] - e) ** 2).sum()) / np.sqrt((e ** 2).sum()))
                 worst[(use_lsgan, n, k)] = (l2, rel(got[k], e))
-                assert l2 < 5e-3 and rel(got[k], e) < 3e-2, (use_lsgan, n, k, l2, rel(got[k], e))
+                assert l2 < 2e-4 and rel(got[k], e) < 2e-4, (use_lsgan, n, k, l2, rel(got[k], e))
             new = net.P.export()
             for k, e in r["params"][n].items():
                 ge = r["grads"][n][k]
@@ -444,8 +519,9 @@ def test_config3_cycle_step_at_its_stated_batch_8(sg):
 
 @pytest.mark.parametrize("cfg", [("config2: 256x256, batch 4, bf16, cycle step", 4, 256, 256, True),
                                  ("config5 shape: 1024x512, batch 2 per GPU, bf16, reference step", 2, 512, 1024, False),
+                                 ("config5 shape: 1024x512, batch 2 per GPU, bf16, CYCLE step (the north_star unit)", 2, 512, 1024, True),
                                  ("odd sizes: 144x208 (not multiples of the tile sizes), f32-free bf16 cycle", 1, 144, 208, True)],
-                         ids=["cfg2", "cfg5", "odd"])
+                         ids=["cfg2", "cfg5", "cfg5_cycle", "odd"])
 def test_other_baseline_configs_run(sg, cfg):
     """BASELINE.json configs[1] and configs[4] (per-GPU share) and a shape that exercises every tail path: one step,
     finite losses, correct shapes, tanh-bounded images.  (1024x512 needs no activation checkpointing in 288 GB:

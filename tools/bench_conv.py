@@ -4,6 +4,7 @@
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import labenv; labenv.select()
 import sggan_amd
 from sggan_amd import kernels as K
 

@@ -3,6 +3,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import labenv; labenv.select()
 import sggan_amd
 from sggan_amd import kernels as K
 from sggan_amd import _abi as A

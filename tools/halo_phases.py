@@ -4,9 +4,9 @@ import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 assert os.environ.get("SGG_ABLATE") == "8", "run with SGG_ABLATE=8"
-os.environ.setdefault("SGG_LIB_PATH", os.path.join(ROOT, "sg-gan-tf2_amd", "libsggan_lab.so"))
 import numpy as np
 import torch
+import labenv; labenv.select("libsggan_lab.so")
 import sggan_amd
 from sggan_amd import kernels as K, _abi as A
 

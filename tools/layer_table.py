@@ -3,6 +3,7 @@ fwd / dgrad / wgrad microseconds and TFLOP/s (algorithmic, un-padded channel cou
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import labenv; labenv.select()
 import sggan_amd
 from sggan_amd import kernels as K
 

@@ -183,11 +183,7 @@ int sgg_bias_grad(const void* dy, float* db, int64_t P, int C, int C_real, int a
 /* ---- instance_norm: tfa.layers.InstanceNormalization ---- module.py:212,216,233,...,308 (spec by name: ops.py:13-22)
  * y = act(gamma*(x-mean)*rstd + beta) (+ residual, added AFTER act; module.py:217 uses act NONE).
  * stats[N][C][2] = (mean, rstd) f32 is written by fwd and read by bwd.
- * ws >= sgg_instnorm_workspace(N, HW, C) bytes.  The instance-norm workspace is a caller-owned buffer of its own: its leading
- * block (N words, padded to 256 bytes) holds the per-image arrival counters of the in-kernel finalize -- the statistics
- * kernel's last-arriving block of an image combines that image's partial sums, so there is no finalize launch -- and must
- * be ZERO when first handed in; every call leaves it zero, so a buffer zero-filled once at allocation and used only for
- * sgg_instnorm_* calls on one stream at a time needs no further care (sgg_instnorm_bwd_partial does not use counters). */
+ * ws >= sgg_instnorm_workspace(N, HW, C) bytes. */
 size_t sgg_instnorm_workspace(int N, int64_t HW, int C);
 int sgg_instnorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* y,
                      float* stats, int N, int64_t HW, int C, float eps, int act, float leak, int dtype,

@@ -47,100 +47,10 @@ static inline int in_rows_per_chunk(int64_t HW) {
 // ws layout: partial[N][chunks][C][2] f32, then sums[N][C][2] and tot[N][C][2] f32 (bwd only)
 static inline int in_chunks(int64_t HW) { int r = in_rows_per_chunk(HW); return (int)((HW + r - 1) / r); }
 
-// Finalize: one 1024-thread block per (32 channels, image); 32 chunk-lanes per channel, each with up to four independent
-// loads in flight, combined in fixed order (deterministic).  (8 lanes walking 16 chunks one dependent L2 load after the
-// other took 5-6 us per launch -- 250 launches per cycle step, 3.7 % of it.)
-#define FIN_CH 32
-#define FIN_LANES 32
-__device__ inline void fin_reduce(const float* partial, int n, int c, int chunks, int C, int lane, double& s1, double& s2) {
-    s1 = 0.0; s2 = 0.0;
-    for (int k0 = lane; k0 < chunks; k0 += FIN_LANES * 4) {
-        float2 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * FIN_LANES;
-            v[u] = k < chunks ? *reinterpret_cast<const float2*>(partial + (((size_t)n * chunks + k) * C + c) * 2) : make_float2(0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
-    }
-}
-
-
-// Finalize INSIDE the statistics kernel: the block that arrives last at an image's counter combines that image's partial rows
-// (the launch boundary + the 4.7 us finalize launch per norm were 220 launches = 4 % of the cycle step).  Hand-off form
-// (cdna_hip_programming.md 5 item 2 / Guideline 16): the partial rows are stored write-through (8-byte agent-scope stores),
-// every wave drains them (s_waitcnt vmcnt(0)), the workgroup's barrier, ONE lane's relaxed agent-scope fetch_add; the block
-// that draws chunks-1 takes ONE agent-scope acquire, resets the counter, and all its waves then read the rows with plain loads
-// behind the barrier.  The combine is the standalone kernels' arithmetic in the same fixed order (32 chunk lanes per channel,
-// f64, lanes summed 0..31), so the result does not depend on which block came last.  tickets: caller-owned, zero on entry,
-// left zero (sgg_instnorm_workspace).
-struct InFinal { unsigned* tickets; float* o1; float* o2; float eps; };       // fwd: o1 = stats; bwd: o1 = sums, o2 = tot
-
-typedef __attribute__((address_space(1))) unsigned long long in_gu64;
-typedef __attribute__((address_space(1))) unsigned in_gu32;
-__device__ inline void in_store_row(float* p, float a, float b, bool write_through) {
-    if (write_through) {
-        const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
-        __hip_atomic_store((in_gu64*)(uintptr_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else { p[0] = a; p[1] = b; }
-}
-
-// true for the block that must finalize image n (all its threads, after a barrier); `flag`: 4 bytes of the block's LDS
-__device__ inline bool in_last_arriver(const InFinal& fin, int n, int nblocks, int* flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // EVERY storing wave drains its write-through rows
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        in_gu32* t = (in_gu32*)(uintptr_t)(fin.tickets + n);
-        const unsigned old = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = old == (unsigned)nblocks - 1u;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // left zero for the next call
-        }
-        *flag = last;
-    }
-    __syncthreads();
-    return *flag != 0;
-}
-
-// The combine of image n by one 256-thread block; red2: >= 16 KB of LDS (double[FIN_LANES][FIN_CH][2]).
-template <bool BWD>
-__device__ inline void in_finalize_image(const float* partial, const InFinal& fin, int n, int64_t HW, int C, int chunks, double* red2) {
-    const int tx = threadIdx.x % FIN_CH, ty = threadIdx.x / FIN_CH;       // ty: 0..7, four of the 32 chunk lanes each
-    for (int cb = 0; cb < C; cb += FIN_CH) {
-        const int c = cb + tx;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int lane = ty + 8 * v;
-            double s1 = 0.0, s2 = 0.0;
-            if (c < C) fin_reduce(partial, n, c, chunks, C, lane, s1, s2);
-            red2[(lane * FIN_CH + tx) * 2] = s1; red2[(lane * FIN_CH + tx) * 2 + 1] = s2;
-        }
-        __syncthreads();
-        if (ty == 0 && c < C) {
-            double s1 = red2[tx * 2], s2 = red2[tx * 2 + 1];
-            for (int l = 1; l < FIN_LANES; ++l) { s1 += red2[(l * FIN_CH + tx) * 2]; s2 += red2[(l * FIN_CH + tx) * 2 + 1]; }
-            const size_t i = ((size_t)n * C + c) * 2;
-            if (!BWD) {
-                double mean = s1 / (double)HW, var = s2 / (double)HW - mean * mean;
-                if (var < 0.0) var = 0.0;
-                fin.o1[i] = (float)mean;
-                fin.o1[i + 1] = (float)(1.0 / sqrt(var + (double)fin.eps));
-            } else {
-                fin.o1[i] = (float)(s1 / (double)HW); fin.o1[i + 1] = (float)(s2 / (double)HW);
-                fin.o2[i] = (float)s1; fin.o2[i + 1] = (float)s2;
-            }
-        }
-        __syncthreads();
-    }
-}
-
 template <typename T, bool BWD, typename TG = T>
 __global__ __launch_bounds__(256) void in_partial_kernel(const char* x, const char* dy, const float* gamma, const float* beta,
                                                          const float* stats, float* partial, int64_t HW, int C, int chunks,
-                                                         int rpc, int act, float leak, InSplit sp, InFinal fin) {
+                                                         int rpc, int act, float leak, InSplit sp) {
     constexpr int VEC = ET<T>::VEC;
     const int CV = C / VEC;                       // channel vectors per pixel
     const int n = blockIdx.y, chunk = blockIdx.x;
@@ -148,9 +58,7 @@ __global__ __launch_bounds__(256) void in_partial_kernel(const char* x, const ch
     const int64_t p0 = (int64_t)chunk * rpc;
     const int64_t p1 = p0 + rpc < HW ? p0 + rpc : HW;
     using AccT = InAcc<T>;
-    __shared__ __attribute__((aligned(16))) AccT red[256][2 * VEC + 1];         // >= 16 KB: reused by the in-kernel finalize
-    static_assert(sizeof(AccT) * 256 * (2 * VEC + 1) >= sizeof(double) * FIN_LANES * FIN_CH * 2 + 16, "finalize scratch");
-    const bool wt = fin.tickets != nullptr;
+    __shared__ AccT red[256][2 * VEC + 1];
     // threads cover (pixel row, channel vector) pairs: cv = item % CV walks fastest
     for (int cvb = 0; cvb < CV; cvb += 256) {
         const int lanes = CV - cvb < 256 ? CV - cvb : 256;       // channel vectors handled in this sweep
@@ -221,14 +129,28 @@ __global__ __launch_bounds__(256) void in_partial_kernel(const char* x, const ch
             for (int r = 0; r < rows; ++r) { a += red[r * lanes + l][e]; b += red[r * lanes + l][VEC + e]; }
             int c = (cvb + l) * VEC + e;
             size_t o = (((size_t)n * chunks + chunk) * C + c) * 2;
-            in_store_row(partial + o, (float)a, (float)b, wt);
+            partial[o] = (float)a; partial[o + 1] = (float)b;
         }
         __syncthreads();
     }
-    if (wt) {
-        char* scratch = reinterpret_cast<char*>(&red[0][0]);
-        if (in_last_arriver(fin, n, chunks, reinterpret_cast<int*>(scratch + sizeof(double) * FIN_LANES * FIN_CH * 2)))
-            in_finalize_image<BWD>(partial, fin, n, HW, C, chunks, reinterpret_cast<double*>(scratch));
+}
+
+// Finalize: one 1024-thread block per (32 channels, image); 32 chunk-lanes per channel, each with up to four independent
+// loads in flight, combined in fixed order (deterministic).  (8 lanes walking 16 chunks one dependent L2 load after the
+// other took 5-6 us per launch -- 250 launches per cycle step, 3.7 % of it.)
+#define FIN_CH 32
+#define FIN_LANES 32
+__device__ inline void fin_reduce(const float* partial, int n, int c, int chunks, int C, int lane, double& s1, double& s2) {
+    s1 = 0.0; s2 = 0.0;
+    for (int k0 = lane; k0 < chunks; k0 += FIN_LANES * 4) {
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * FIN_LANES;
+            v[u] = k < chunks ? *reinterpret_cast<const float2*>(partial + (((size_t)n * chunks + k) * C + c) * 2) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
     }
 }
 
@@ -507,11 +429,9 @@ static int in_rows_per_block(int N, int64_t HW, int C, int vec) {
 
 extern "C" {
 
-// ws layout: [arrival counters: N words, padded to 256 B][partial[N][chunks][C][2]][sums[N][C][2]][tot[N][C][2]] (f32)
-static inline size_t in_ticket_bytes(int N) { return align_up((size_t)N * sizeof(unsigned), 256); }
 size_t sgg_instnorm_workspace(int N, int64_t HW, int C) {
     if (N <= 0 || HW <= 0 || C <= 0) return 0;
-    return in_ticket_bytes(N) + ((size_t)N * in_chunks(HW) * C * 2 + (size_t)N * C * 4) * sizeof(float);
+    return ((size_t)N * in_chunks(HW) * C * 2 + (size_t)N * C * 4) * sizeof(float);
 }
 
 static int instnorm_fwd_impl(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* stats,
@@ -529,15 +449,16 @@ static int instnorm_fwd_impl(const void* x, const float* gamma, const float* bet
         return sgg_check_launch();
     }
     int chunks = in_chunks(HW);
-    float* partial = (float*)((char*)ws + in_ticket_bytes(N));
+    float* partial = (float*)ws;
     int rpb = in_rows_per_block(N, HW, C, 0);
     dim3 gp(chunks, N), ga((unsigned)((HW + rpb - 1) / rpb), N);
-    const InFinal fin{(unsigned*)ws, stats, nullptr, eps};      // the last block of each image finalizes: no finalize launch
     if (dtype == SGG_BF16) {
-        hipLaunchKernelGGL((in_partial_kernel<bf16, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak, sp, fin);
+        hipLaunchKernelGGL((in_partial_kernel<bf16, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak, sp);
+        hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, stats, HW, C, chunks, eps);
         sgg_launch_timed(in_apply_kernel<bf16, false>, ga, dim3(256), 0u, s, (const char*)x, (const char*)nullptr, (const char*)residual, gamma, beta, (const float*)stats, (const float*)nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{}, sp);
     } else if (dtype == SGG_F32) {
-        hipLaunchKernelGGL((in_partial_kernel<float, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak, sp, fin);
+        hipLaunchKernelGGL((in_partial_kernel<float, false>), gp, dim3(256), 0, s, (const char*)x, nullptr, gamma, beta, nullptr, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak, sp);
+        hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, stats, HW, C, chunks, eps);
         hipLaunchKernelGGL((in_apply_kernel<float, false>), ga, dim3(256), 0, s, (const char*)x, nullptr, (const char*)residual, gamma, beta, stats, nullptr, (char*)y, HW, C, rpb, act, leak, InParamGrad{}, sp);
     } else return SGG_EINVAL;
     return sgg_check_launch();
@@ -566,13 +487,12 @@ static int instnorm_bwd_impl(const void* dy, const void* x, const float* gamma, 
     if (!ws || ws_bytes < sgg_instnorm_workspace(N, HW, C)) return SGG_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     int chunks = in_chunks(HW);
-    float* partial = (float*)((char*)ws + in_ticket_bytes(N));
+    float* partial = (float*)ws;
     float* sums = partial + (size_t)N * chunks * C * 2;
     float* tot = sums + (size_t)N * C * 2;
     int rpb = in_rows_per_block(N, HW, C, 0);
     dim3 gp(chunks, N), ga((unsigned)((HW + rpb - 1) / rpb), N);
     const InParamGrad pg{tot, dgamma, dbeta, N, C_real, accumulate};
-    const InFinal fin{(unsigned*)ws, sums, tot, 0.f};
     if (dtype != SGG_BF16 && dtype != SGG_F32) return SGG_EINVAL;
     if (in_use_fused(HW)) {
         const int vec = dtype == SGG_BF16 ? 8 : 4;
@@ -583,10 +503,12 @@ static int instnorm_bwd_impl(const void* dy, const void* x, const float* gamma, 
         return sgg_check_launch();
     }
     if (dtype == SGG_BF16) {
-        hipLaunchKernelGGL((in_partial_kernel<bf16, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak, sp, fin);
+        hipLaunchKernelGGL((in_partial_kernel<bf16, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak, sp);
+        hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, sums, tot, HW, C, chunks);
         hipLaunchKernelGGL((in_apply_kernel<bf16, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg, sp);
     } else if (dtype == SGG_F32) {
-        hipLaunchKernelGGL((in_partial_kernel<float, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak, sp, fin);
+        hipLaunchKernelGGL((in_partial_kernel<float, true>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak, sp);
+        hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, sums, tot, HW, C, chunks);
         hipLaunchKernelGGL((in_apply_kernel<float, true>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg, sp);
     } else return SGG_EINVAL;
     return sgg_check_launch();
@@ -603,14 +525,14 @@ static int instnorm_bwd_mixed_impl(const float* dy, const void* x, const float* 
     if (!ws || ws_bytes < sgg_instnorm_workspace(N, HW, C)) return SGG_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     int chunks = in_chunks(HW);
-    float* partial = (float*)((char*)ws + in_ticket_bytes(N));
+    float* partial = (float*)ws;
     float* sums = partial + (size_t)N * chunks * C * 2;
     float* tot = sums + (size_t)N * C * 2;
     int rpb = in_rows_per_block(N, HW, C, 0);
     dim3 gp(chunks, N), ga((unsigned)((HW + rpb - 1) / rpb), N);
     const InParamGrad pg{tot, dgamma, dbeta, N, C_real, accumulate};
-    const InFinal fin{(unsigned*)ws, sums, tot, 0.f};
-    hipLaunchKernelGGL((in_partial_kernel<bf16, true, float>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak, sp, fin);
+    hipLaunchKernelGGL((in_partial_kernel<bf16, true, float>), gp, dim3(256), 0, s, (const char*)x, (const char*)dy, gamma, beta, stats, partial, HW, C, chunks, in_rows_per_chunk(HW), act, leak, sp);
+    hipLaunchKernelGGL(in_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, s, partial, sums, tot, HW, C, chunks);
     hipLaunchKernelGGL((in_apply_kernel<bf16, true, float>), ga, dim3(256), 0, s, (const char*)x, (const char*)dy, nullptr, gamma, beta, stats, sums, (char*)dx, HW, C, rpb, act, leak, pg, sp);
     return sgg_check_launch();
 }

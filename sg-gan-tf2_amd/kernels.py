@@ -78,24 +78,9 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
-_WS_IN = {}
-
-
-def in_workspace(nbytes: int, device) -> torch.Tensor:
-    """Scratch of the instance-norm calls (sgg_instnorm_workspace).  Its leading block holds the per-image arrival counters of
-    the in-kernel finalize: zero when allocated, left zero by every call, and used by nothing else -- hence a buffer of its
-    own rather than the shared scratch."""
-    key = torch.device(device).index or 0
-    ws = _WS_IN.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        _WS_IN[key] = ws
-    return ws
-
-
 def workspace_refs():
     """The scratch buffers currently in use (a recorded StepProgram holds them: their addresses are in its launches)."""
-    return list(_WS.values()) + list(_WS_IN.values())
+    return list(_WS.values())
 
 
 def same_pads(n_in: int, k: int, s: int):
@@ -383,7 +368,7 @@ def instnorm_fwd(x, gamma, beta, residual=None, eps=1e-3, act=A.ACT_NONE, leak=0
     assert gamma.numel() == Cp and beta.numel() == Cp, "gamma/beta must be channel-padded"
     y = torch.empty_like(x)
     stats = torch.empty((N, Cp, 2), dtype=torch.float32, device=x.device)
-    ws = in_workspace(int(A.lib().sgg_instnorm_workspace(N, H * W, Cp)), x.device)
+    ws = workspace(int(A.lib().sgg_instnorm_workspace(N, H * W, Cp)), x.device)
     pr = _prof("instnorm_fwd", (tuple(x.shape), residual is not None))
     if pr: pr.start()
     A.check(A.lib().sgg_instnorm_fwd(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(stats), N, H * W, Cp, eps, act, leak,
@@ -409,7 +394,7 @@ def instnorm_fwd_partial(x, partial, gamma, beta, residual=None, eps=1e-3, act=A
 def instnorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, accumulate=False, act=A.ACT_NONE, leak=0.0):
     N, H, W, Cp = x.shape
     dx = torch.empty_like(x)
-    ws = in_workspace(int(A.lib().sgg_instnorm_workspace(N, H * W, Cp)), x.device)
+    ws = workspace(int(A.lib().sgg_instnorm_workspace(N, H * W, Cp)), x.device)
     if dy.dtype == torch.float32 and x.dtype == torch.bfloat16:        # mixed mode: f32 gradient chain, bf16 tensors
         A.check(A.lib().sgg_instnorm_bwd_mixed(_p(dy), _p(x), _p(gamma), _p(beta), _p(stats), _p(dx), _p(dgamma), _p(dbeta), N, H * W, Cp,
                                                dgamma.numel(), int(accumulate), act, leak, _p(ws), ws.numel(), _s()), "instnorm_bwd_mixed")
@@ -437,7 +422,7 @@ def instnorm_fwd_pair(x, gamma, beta, gamma2, beta2, nsplit, residual=None, eps=
     assert gamma.numel() == Cp and gamma2.numel() == Cp and 0 < nsplit < N
     y = torch.empty_like(x)
     stats = torch.empty((N, Cp, 2), dtype=torch.float32, device=x.device)
-    ws = in_workspace(int(A.lib().sgg_instnorm_workspace(N, H * W, Cp)), x.device)
+    ws = workspace(int(A.lib().sgg_instnorm_workspace(N, H * W, Cp)), x.device)
     pr = _prof("instnorm_fwd_pair", (tuple(x.shape), residual is not None))
     if pr: pr.start()
     A.check(A.lib().sgg_instnorm_fwd_pair(_p(x), _p(gamma), _p(beta), _p(gamma2), _p(beta2), nsplit, _p(residual), _p(y), _p(stats), N, H * W, Cp,
@@ -464,7 +449,7 @@ def instnorm_bwd_pair(dy, x, gamma, beta, gamma2, beta2, nsplit, stats, dgamma, 
     N, H, W, Cp = x.shape
     assert dy.dtype == x.dtype and dgamma.numel() == dgamma2.numel() and 0 < nsplit < N
     dx = torch.empty_like(x)
-    ws = in_workspace(int(A.lib().sgg_instnorm_workspace(N, H * W, Cp)), x.device)
+    ws = workspace(int(A.lib().sgg_instnorm_workspace(N, H * W, Cp)), x.device)
     A.check(A.lib().sgg_instnorm_bwd_pair(_p(dy), _p(x), _p(gamma), _p(beta), _p(gamma2), _p(beta2), nsplit, _p(stats), _p(dx), _p(dgamma), _p(dbeta),
                                           _p(dgamma2), _p(dbeta2), N, H * W, Cp, dgamma.numel(), int(accumulate), act, leak, dt(x),
                                           _p(ws), ws.numel(), _s()), "instnorm_bwd_pair")

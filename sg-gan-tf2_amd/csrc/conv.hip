@@ -721,9 +721,6 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
 #ifndef H3_HALO_HALF
 #define H3_HALO_HALF 1                                 // ... and which half the halo-row DMAs (the other half measured 3-6 % slower:
 #endif                                                 //     the non-issuers' early MFMAs are what covers the issuers' DMA phase)
-#ifndef H3_SPREAD
-#define H3_SPREAD 0                                    // 1: every wave issues its share of the tile's DMAs BETWEEN its MFMA groups (no issuer waves)
-#endif
 #ifndef H3_GJ
 #define H3_GJ 4                                        // pixel fragments per MFMA group of the main loop (x 4 weight fragments = 16 MFMAs)
 #endif
@@ -889,28 +886,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         // their MFMAs.  (Not the same as splitting each wave's issue in time: waves 4-7 issuing their own share half way
         // through the tile measured 7 % slower; waves 0-3 issuing the halo rows, or 2-4 of the 8 weight DMAs per SIMD pair,
         // AFTER their MFMAs -- in the ~1 000 cycles they wait at the barrier -- measured 2-3 % slower.)
-        int ntap_ = tap + 1, nchk_ = chunk;
-        if (ntap_ == 9) { ntap_ = 0; ++nchk_; }
-        // H3_SPREAD: the same DMAs, but every wave issues ITS share (weights: rows 8(wave + 8j); halo row pieces wave, wave + 8,
-        // wave + 16) in front of MFMA group g -- one to three 1 KB instructions per group -- so that both waves of a SIMD multiply
-        // through the whole tile and each one's issue stalls fall into the other's MFMAs
-        auto spread_issue = [&](int g) {
-            if (!(abl == 0 || abl == 2)) return;
-            if (t + 1 < ntiles) {
-                const int stg = (t + 1) & 1, wt = MODE == MODE_FWD ? ntap_ : 8 - ntap_;
-                if (g == 0) { load_w(stg, nchk_, wt, wave, 16); }                      // rows 8*wave, 8*(wave+16)
-                if (g == 1) { load_w(stg, nchk_, wt, wave + 8, 32); }                  // rows 8*(wave+8)
-                if (g == 2) { load_w(stg, nchk_, wt, wave + 24, 32); }                 // rows 8*(wave+24)
-            }
-            if (g == 0) {
-                if (tap == 0 && chunk > 0) load_halo_row(2, chunk, wave, 8);
-                if (tap == 3 && chunk > 0) load_halo_row(3, chunk, wave, 8);
-                if (tap == 6 && chunk + 1 < nchunk) load_halo_row(1, chunk + 1, wave, 8);
-            }
-            if (g == 1 && tap == 3 && chunk + 1 < nchunk) load_halo_row(0, chunk + 1, wave, 8);
-            if (g == 2 && tap == 3 && chunk + 1 < nchunk) load_patch(chunk + 1, wave, 8);
-        };
-        if (!H3_SPREAD && (abl == 0 || abl == 2)) {
+        if (abl == 0 || abl == 2) {
             const int vw = wave & 3;
             if ((wave >> 2) == H3_ISSUER_HALF) {           // the weight tile: 8 DMA instructions per issuer wave and tile
                 int ntap = tap + 1, nchk = chunk;
@@ -973,7 +949,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
 #pragma unroll
                     for (int i = 0; i < NI; ++i) fw[1][i] = ld16(bQ + i * 16 * BKB + (((fq + 4) ^ fswQ) << 4));
                 }
-                if (H3_SPREAD) spread_issue(g);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int jj = 0; jj < GJ; ++jj)

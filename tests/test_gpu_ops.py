@@ -326,6 +326,16 @@ def test_seg_class_map_reference_fixtures_bit_exact(sg):
     got = sc.preprocess(img).detach().cpu().numpy()
     assert np.array_equal(got, O.seg_class_map(img))
     assert sc.preprocess(np.zeros((0, 4, 3), np.uint8)).shape == (0, 4)
+    # ragged pixel counts (the 4-pixels-per-thread kernel + its scalar tail) and pointers that are not 4-byte aligned (scalar path)
+    from sggan_amd import kernels as K
+    for ch in (3, 4):
+        for npx in (1, 2, 3, 4, 5, 7, 8, 1023):
+            src = np.concatenate([pal[rng.integers(0, len(pal), npx)], np.full((npx, 1), 255, np.uint8)], 1)[:, :ch]
+            for off in (0, 1, 2):
+                buf = torch.zeros(off + npx * ch, dtype=torch.uint8, device="cuda")
+                buf[off:] = torch.as_tensor(np.ascontiguousarray(src).ravel()).cuda()
+                got = K.seg_class_map(buf[off:].view(npx, ch)).cpu().numpy()
+                assert np.array_equal(got, O.seg_class_map(np.ascontiguousarray(src)[None, :, :])[0]), (ch, npx, off)
 
 
 def test_onehot_resample_bit_exact(sg):

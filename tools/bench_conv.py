@@ -36,6 +36,23 @@ if "dgrad_stats" in a.ops or "in_partial" in a.ops:      # data gradient + the n
     dxs, part = K.conv_dgrad_stats(g, dy, wd, x, nx, nst, gam, bet, AB.ACT_RELU, 0.0)
     fns["in_bwd"] = lambda: K.instnorm_bwd(dxs, nx, gam, bet, nst, dgm, dbt, False, AB.ACT_RELU)
     fns["in_bwd_partial"] = lambda: K.instnorm_bwd_partial(dxs, nx, part, gam, bet, nst, dgm, dbt, False, AB.ACT_RELU)
+if any(o in a.ops.split(",") for o in ("fwd_pair", "dgrad_pair", "wgrad_pair2")):
+    # the launches the paired cycle step makes: a stacked batch of two networks (images [:n/2] / [n/2:]) with two weight sets
+    assert a.n % 2 == 0
+    h = a.n // 2
+    w2 = torch.randn((a.r, a.r, a.c, a.k), device="cuda") / (a.r * a.r * a.c) ** 0.5
+    wf2, wd2 = K.pack_weights(w2, Cp, Kp, dt)
+    bias = torch.zeros(Kp, device="cuda")
+    fns["fwd_pair"] = lambda: K.conv_fwd_stats_pair(g, x, wf, bias, wf2, bias, h)
+    fns["dgrad_pair"] = lambda: K.conv_dgrad_pair(g, dy, wd, wd2, h, x)                      # + the skip-gradient addend, as in the step
+    gh = K.conv_geom(h, a.h, a.w, Cp, Kp, a.r, a.r, a.stride, pad, refl, dt)
+    xs = [torch.randn(gh.x_shape, device="cuda").to(dt) for _ in range(4)]
+    ds = [torch.randn(gh.y_shape, device="cuda").to(dt) for _ in range(4)]
+    dw2 = torch.empty_like(w)
+    fns["wgrad_pair2"] = lambda: K.conv_wgrad_pair2(gh, (xs[0], ds[0], xs[1], ds[1], dw), (xs[2], ds[2], xs[3], ds[3], dw2))
+    FLOPS = {"wgrad_pair2": 4 * 2.0 * gh.y_shape[0] * gh.y_shape[1] * gh.y_shape[2] * a.k * a.r * a.r * a.c}
+else:
+    FLOPS = {}
 for op in a.ops.split(","):
     f = fns[op]
     for _ in range(5):
@@ -47,4 +64,5 @@ for op in a.ops.split(","):
         f()
     e.record(); torch.cuda.synchronize()
     ms = s.elapsed_time(e) / a.iters
-    print(f"{op:6s} {ms*1e3:8.1f} us  {flops/ms/1e9:8.1f} TFLOP/s  ({flops/1e9:.1f} GFLOP)", flush=True)
+    fl = FLOPS.get(op, flops)
+    print(f"{op:6s} {ms*1e3:8.1f} us  {fl/ms/1e9:8.1f} TFLOP/s  ({fl/1e9:.1f} GFLOP)", flush=True)

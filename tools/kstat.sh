@@ -10,7 +10,7 @@ import csv, glob
 f = glob.glob("$O/raw/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-for r in rows[:45]:
+for r in rows[:int("${KSTAT_ROWS:-80}")]:
     print(f"{float(r['TotalDurationNs'])/tot*100:5.1f}%  calls {int(r['Calls']):5d}  avg {float(r['AverageNs'])/1e3:8.1f} us  {r['Name'][:90]}")
 PY
 rm -rf $O/raw

@@ -8,10 +8,16 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 root = sys.argv[1]
-MAIN = {"fwd": ("conv3x3_halo_gemm", "conv_gemm_glds"), "dgrad": ("conv3x3_halo_gemm", "conv_gemm_glds"), "wgrad": ("conv3x3_wgrad_halo", "conv_wgrad_glds")}
-AUX = {"dgrad": ("fold_halo_gather", "fold_gather"), "wgrad": ("wgrad_reduce",)}
+OPS = sys.argv[2].split(",") if len(sys.argv) > 2 else ["fwd", "dgrad", "wgrad"]
+NIMG = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+_G = ("conv3x3_halo_gemm", "conv_gemm_glds")
+_W = ("conv3x3_wgrad_halo", "conv_wgrad_glds")
+MAIN = {"fwd": _G, "dgrad": _G, "wgrad": _W, "fwd_pair": _G, "dgrad_pair": _G, "wgrad_pair2": _W}
+AUX = {"dgrad": ("fold_halo_gather", "fold_gather"), "wgrad": ("wgrad_reduce",), "dgrad_pair": ("fold_halo_gather", "fold_gather"), "wgrad_pair2": ("wgrad_reduce",)}
+GF8 = 77.309411328                                    # GFLOP of one 8-image residual conv
+GFLOP = {"wgrad_pair2": 2 * NIMG / 8 * GF8}           # two networks x two applications of NIMG/2 images each
 out = {}
-for op in ("fwd", "dgrad", "wgrad"):
+for op in OPS:
     vals, aux = defaultdict(list), defaultdict(list)
     for f in glob.glob(os.path.join(root, op + "_*", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -32,7 +38,9 @@ for op in ("fwd", "dgrad", "wgrad"):
         a = {k: mean(v) for k, v in aux.items()}
         if a.get("FETCH_SIZE") is not None and a.get("WRITE_SIZE") is not None:
             e["aux_kernel_hbm_bytes_per_launch"] = (2.0 * a["FETCH_SIZE"] + a["WRITE_SIZE"]) * 1024.0
-    e["note"] = ("rocprofv3 --pmc (separate passes, --kernel-trace only) on tools/bench_conv.py, N=8 64x128 C=K=256 3x3; FETCH_SIZE doubled "
-                 "(gfx950 counts 128-B requests as 64 B); algorithmic bytes 33.6 MB in + 33.6 MB out + 1.2 MB weights")
+    e["gflop_per_launch"] = GFLOP.get(op, NIMG / 8 * GF8)
+    e["note"] = (f"rocprofv3 --pmc (separate passes, --kernel-trace only) on tools/bench_conv.py --ops {op} --n {NIMG}, 64x128 C=K=256 3x3; FETCH_SIZE doubled "
+                 "(gfx950 counts 128-B requests as 64 B); algorithmic bytes per 8 images and application: 33.6 MB in + 33.6 MB out (forward / data "
+                 "gradient; + 33.6 MB for the skip-gradient addend in dgrad_pair) or 2 x 33.6 MB in (weight gradient), + 1.2 MB of weights per network")
     out["res_conv_" + op] = e
 print(json.dumps(out, indent=1))

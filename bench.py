@@ -296,7 +296,6 @@ def main():
     ap.add_argument("--no-reference-leg", action="store_true", help="skip the reference-mode step timed beside the cycle headline (profiling: keeps the kernel statistics to the cycle step)")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step from captured HIP graphs (default); 0: eager per-launch dispatch from Python")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the short f32 (the reference's precision) run of the same step reported as f32_step")
-    ap.add_argument("--pair-streams", type=int, default=None, help="1/0: queue the two networks' per-half launches of the lockstep pairs on two HIP streams (default: the package's)")
     ap.add_argument("--lib", default=None, help="A/B timing: bind this build of the library instead of the in-tree libsggan.so")
     a = ap.parse_args()
 
@@ -322,8 +321,7 @@ def main():
     from sggan_amd import kernels as K
     def make_model(mode, dtype=None):
         m = sggan_amd.sggan(sggan_amd.default_args(dtype=dtype or a.dtype, device=f"cuda:{local}", image_height=a.height,
-                                                   image_width=a.width, batch_size=a.batch, cycle=(mode == "cycle"), graph=bool(a.graph), mixed=bool(a.mixed),
-                                                   **({} if a.pair_streams is None else {"pair_streams": bool(a.pair_streams)})))
+                                                   image_width=a.width, batch_size=a.batch, cycle=(mode == "cycle"), graph=bool(a.graph), mixed=bool(a.mixed)))
         if dist is not None:
             m.enable_data_parallel()
         set_inputs(m, a.batch, a.height, a.width, 19 + rank)

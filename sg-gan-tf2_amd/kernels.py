@@ -68,34 +68,9 @@ def host(fn):
 
 
 
-# Two independent launch sequences (the two networks' halves of a lockstep pair, module._PairUnit) may be queued on two HIP
-# streams so that the GPU can run them side by side: the second on a side stream forked from and joined back into the
-# current one (events; under stream capture the side stream joins the capture and the graph gets two parallel branches).
-# Worth it where one half alone does not fill the chip or leaves a ragged tail (the discriminators' small maps).
-PAIR_STREAMS = False
-_SIDE = {}
-
-
-def run_pair(first, second, device):
-    if not PAIR_STREAMS:
-        first(); second()
-        return
-    dev = torch.device(device)
-    cur = torch.cuda.current_stream(dev)
-    side = _SIDE.get(dev.index or 0)
-    if side is None:
-        side = _SIDE[dev.index or 0] = torch.cuda.Stream(dev)
-    side.wait_stream(cur)                      # fork: everything queued so far precedes `second`
-    with torch.cuda.stream(side):
-        second()
-    first()
-    cur.wait_stream(side)                      # join
-
-
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Scratch buffer shared by all launches of one stream of one device (in-order reuse within a stream is safe; the side
-    stream of run_pair has its own)."""
-    key = (torch.device(device).index or 0, _raw_stream(_raw_device()) if _raw_stream is not None else 0)
+    """Per-device scratch buffer shared by all launches (single stream => in-order reuse is safe)."""
+    key = torch.device(device).index or 0
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -30,7 +30,7 @@ def default_args(**over):
              segment_class=34, beta1=0.5, lr=0.0002, L1_lambda=10.0, Lg_lambda=5.0, use_resnet=True, use_pix2pix=False,
              use_lsgan=True, ratio_gan2seg=10, max_size=50, phase="train", dataset_dir="city",
              dtype="bf16", device="cuda", n_blocks=9, seed=19, graph=False, mixed=False, paired=True,
-             fuse_in_stats=True, fuse_in_bwd=False, g_buckets=3, keep_tapes=False, pair_streams=False)
+             fuse_in_stats=True, fuse_in_bwd=False, g_buckets=3, keep_tapes=False)
     a.update(over)
     return SimpleNamespace(**a)
 
@@ -109,9 +109,6 @@ class sggan(object):
         # diagnostics: keep the last step's forward records (saved activations) reachable as ``self.tapes`` -- the parity tests
         # read from them which side of each ReLU / LeakyReLU kink the kernels took (tests/kink_helpers.py).  Off: they are dropped
         # when the step returns, so their memory is reused at once.
-        # lockstep pairs: the two networks' per-half launches (convolutions without a paired kernel form, their weight / bias
-        # gradients) on two HIP streams -- kernels.run_pair
-        K.PAIR_STREAMS = bool(g("pair_streams", False))
         self.keep_tapes = bool(g("keep_tapes", False))
         self.tapes = None
         # HIP-graph replay of the step (graph.py): recorded at the first train_step after enable_graph()

@@ -616,19 +616,18 @@ class _PairUnit:
         xc = torch.empty((2 * n,) + tuple(g.y_shape[1:]), dtype=x.dtype, device=x.device)
         if ua.kind == "conv" and ua.norm and g.stats_chunks and ua.net.fuse_in_stats:
             part = torch.empty((2 * n, g.stats_chunks, g.y_shape[3], 2), dtype=torch.float32, device=x.device)
-            def half_stats(u, sl):
+            for u, sl in halves:
                 wf, _ = u.packed(x.dtype)
-                return lambda: K.conv_fwd_stats(g, x[sl], wf, u.net.P.p(u.name + "_b"), out=xc[sl], out_partial=part[sl])
-            K.run_pair(half_stats(*halves[0]), half_stats(*halves[1]), x.device)
+                K.conv_fwd_stats(g, x[sl], wf, u.net.P.p(u.name + "_b"), out=xc[sl], out_partial=part[sl])
             y, stats = K.instnorm_fwd_partial_pair(xc, part, PA.p(na + "_g"), PA.p(na + "_beta"), PB.p(nb + "_g"), PB.p(nb + "_beta"), n,
                                                    residual, ua.net.eps, ua.act, ua.leak)
             return y, (g, x, xc, stats)
-        def half_fwd(u, sl):
-            wf, wd = u.packed(x.dtype)                     # (packing happens here, on the current stream, not in the closure)
+        for u, sl in halves:
+            wf, wd = u.packed(x.dtype)
             if u.kind == "conv":
-                return lambda: K.conv_fwd(g, x[sl], wf, u.net.P.p(u.name + "_b"), fused_act, u.leak, out=xc[sl])
-            return lambda: K.deconv_fwd(g, x[sl], wd, u.net.P.p(u.name + "_b"), fused_act, u.leak, out=xc[sl])
-        K.run_pair(half_fwd(*halves[0]), half_fwd(*halves[1]), x.device)
+                K.conv_fwd(g, x[sl], wf, u.net.P.p(u.name + "_b"), fused_act, u.leak, out=xc[sl])
+            else:
+                K.deconv_fwd(g, x[sl], wd, u.net.P.p(u.name + "_b"), fused_act, u.leak, out=xc[sl])
         if not ua.norm:
             return xc, (g, x, xc, None)
         y, stats = K.instnorm_fwd_pair(xc, PA.p(na + "_g"), PA.p(na + "_beta"), PB.p(nb + "_g"), PB.p(nb + "_beta"), n,
@@ -654,7 +653,8 @@ class _PairUnit:
         else:
             dxc = K.act_bwd(dy, xc, ua.act, ua.leak) if ua.act != A.ACT_NONE else dy
             if param_grads:
-                K.run_pair(*[(lambda u=u, sl=sl: K.bias_grad(dxc[sl], u.net.P.g(u.name + "_b"), accumulate=True)) for u, sl in halves], x.device)
+                for u, sl in halves:
+                    K.bias_grad(dxc[sl], u.net.P.g(u.name + "_b"), accumulate=True)
         if param_grads:
             # both networks have this layer's first application waiting (pair_wgrads): all four weight gradients in ONE launch
             pa, pb = ua._pending, ub._pending
@@ -664,18 +664,19 @@ class _PairUnit:
                                            (pb[1], pb[2], x[halves[1][1]], dxc[halves[1][1]], PB.g(nb + "_w")), accumulate=True):
                 ua._pending = ub._pending = None
             else:
-                K.run_pair(*[(lambda u=u, sl=sl: u.weight_grad(g, x[sl], dxc[sl])) for u, sl in halves], x.device)
+                for u, sl in halves:
+                    u.weight_grad(g, x[sl], dxc[sl])
         if not want_dx:
             return None
         if ua.kind == "conv" and ua.geom(x).pair_ok:
             return K.conv_dgrad_pair(ua.geom(x), dxc, ua.packed(x.dtype)[1], ub.packed(x.dtype)[1], n, addend)
         dx = torch.empty((2 * n,) + tuple(g.x_shape[1:]), dtype=dxc.dtype, device=dxc.device)
-        def half_dgrad(u, sl):
+        for u, sl in halves:
             wf, wd = u.packed(x.dtype)
             if u.kind == "conv":
-                return lambda: K.conv_dgrad(g, dxc[sl], wd, None if addend is None else addend[sl], out=dx[sl])
-            return lambda: K.deconv_dgrad(g, dxc[sl], wf, out=dx[sl])
-        K.run_pair(half_dgrad(*halves[0]), half_dgrad(*halves[1]), x.device)
+                K.conv_dgrad(g, dxc[sl], wd, None if addend is None else addend[sl], out=dx[sl])
+            else:
+                K.deconv_dgrad(g, dxc[sl], wf, out=dx[sl])
         if ua.kind != "conv" and addend is not None:
             dx = K.add(dx, addend)
         return dx

@@ -721,6 +721,9 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
 #ifndef H3_HALO_HALF
 #define H3_HALO_HALF 1                                 // ... and which half the halo-row DMAs (the other half measured 3-6 % slower:
 #endif                                                 //     the non-issuers' early MFMAs are what covers the issuers' DMA phase)
+#ifndef H3_ROT
+#define H3_ROT 1                                       // halo rows: 16-byte chunk c of row r sits at position (c + (r & 6)) & 7 (a rotation) instead of c ^ ((r >> 1) & 7)
+#endif
 #ifndef H3_GJ
 #define H3_GJ 4                                        // pixel fragments per MFMA group of the main loop (x 4 weight fragments = 16 MFMAs)
 #endif
@@ -808,8 +811,17 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             bool ok = rowok && hp < H3_TW + 2;
             if (mirror) wi = wi < 0 ? -wi : (wi >= a.W ? 2 * (a.W - 1) - wi : wi);
             else ok = ok && (unsigned)wi < (unsigned)a.W;
-            const int key = (((k * H3_PITCH + hp) >> 1) & 7);
-            const char* src = ok ? rowp + (size_t)wi * SC * 2 + ((hpos ^ key) << 4) : zero;
+            // Swizzle of the halo image.  A ds_read_b128 is serviced in four groups of 16 lanes that pair k-quarter fq = 0 (2) of
+            // eight fragment rows with fq = 1 (3) of the other eight; per half bank line (row parity) a group therefore reads
+            // chunk c of rows 2(m0 + {0,1,6,7}) and chunk c + 1 of rows 2(m0 + {2,3,4,5}), where m0 moves with the tap column
+            // (fragment base = halo column + 0 / 1 / 2).  With the XOR key (r >> 1) & 7 those eight positions are distinct only
+            // for even m0 -- the 31-34 % conflict replays of round 2 (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE) on two tap columns
+            // of three.  Rotating instead, position = (c + 2 * (r >> 1)) & 7, gives 2 m0 + {0,2,4,6} and 2 m0 + 1 + {4,6,0,2}:
+            // all evens and all odds, distinct for EVERY m0.  The DMA writes LDS linearly, so the rotation goes on the source
+            // address: position hpos of row r holds chunk (hpos - (r & 6)) & 7.
+            const int hrow_ = k * H3_PITCH + hp;
+            const int schunk = H3_ROT ? ((hpos - (hrow_ & 6)) & 7) : (hpos ^ ((hrow_ >> 1) & 7));
+            const char* src = ok ? rowp + (size_t)wi * SC * 2 + (schunk << 4) : zero;
             dma16_to_lds(src, (__attribute__((address_space(3))) void*)(lH + (k * H3_PITCH + q * 8) * 128));
         }
     };
@@ -908,7 +920,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         // the data gradient, so both modes walk the halo rows in the same order (the refill schedule relies on it)
         const int hr = wm + r;                                             // halo row of this wave's output row
         const int hc = frow + sx;                                          // halo column of fragment 0
-        const int fswP = (((hr * H3_PITCH + hc) >> 1) & 7);                // same for every fragment (16 | fragment step)
+        const int fswP = H3_ROT ? ((hr * H3_PITCH + hc) & 6) : (((hr * H3_PITCH + hc) >> 1) & 7);   // same for every fragment (16 | fragment step)
         const char* bP = sH + (hr * H3_PITCH + hc) * 128;
         const char* bQ = sB + (t & 1) * (256 * 128) + (wn * WN + frow) * 128;
         // FOLD: the lanes holding pixel column 1 (fragment 0) / W-2 (fragment MI-1) read their patch row instead
@@ -918,7 +930,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         const int keyL = (peL >> 1) & 7, keyR = (peR >> 1) & 7;
         const bool isL = hasL && frow == 1, isR = hasR && frow == 14;
         auto ldP = [&](int j, int kk) -> u32x4 {
-            const char* p = bP + j * 16 * BKB + (((fq + 4 * kk) ^ fswP) << 4);
+            const char* p = bP + j * 16 * BKB + ((H3_ROT ? ((fq + 4 * kk + fswP) & 7) : ((fq + 4 * kk) ^ fswP)) << 4);
             if (FOLD) {
                 if (j == 0 && isL) p = pL + (((fq + 4 * kk) ^ keyL) << 4);
                 if (j == MI - 1 && isR) p = pR + (((fq + 4 * kk) ^ keyR) << 4);
@@ -1266,8 +1278,10 @@ __global__ __launch_bounds__(512) void deconv_s2_halo_kernel(ConvArgs a, int tot
             const int hp = cg * 8 + hsub;
             const int hi = T.i0 - 1 + k, wi = T.j0 - 1 + hp;
             const bool ok = hp < S2_TJ + 2 && (unsigned)hi < (unsigned)a.Ho && (unsigned)wi < (unsigned)a.Wo;
-            const int key = ((k * S2_PITCH + hp) >> 1) & 7;
-            const char* src = ok ? a.src + ((((size_t)T.img * a.Ho + hi) * a.Wo + wi) * SC + chunk * 64) * 2 + ((hpos ^ key) << 4) : zero;
+            // rotation swizzle of the halo rows (conflict-free fragment reads for every tap shift; see conv3x3_halo_gemm_kernel)
+            const int hrow_ = k * S2_PITCH + hp;
+            const int schunk = H3_ROT ? ((hpos - (hrow_ & 6)) & 7) : (hpos ^ ((hrow_ >> 1) & 7));
+            const char* src = ok ? a.src + ((((size_t)T.img * a.Ho + hi) * a.Wo + wi) * SC + chunk * 64) * 2 + (schunk << 4) : zero;
             dma16_to_lds(src, (__attribute__((address_space(3))) void*)(dstb + (k * S2_PITCH + cg * 8) * 128));
         }
     };
@@ -1322,7 +1336,7 @@ __global__ __launch_bounds__(512) void deconv_s2_halo_kernel(ConvArgs a, int tot
                 const int bs = (sx + PL) & 1, ds = (bs + PL - sx) / 2;
                 const int cls = ar * 2 + bs;
                 const int hrow = (wave + dr + 1) * S2_PITCH + (ds + 1) + frow;   // halo pixel of fragment 0, this lane
-                const int fswP = (hrow >> 1) & 7;
+                const int fswP = H3_ROT ? (hrow & 6) : ((hrow >> 1) & 7);
                 const char* bP = hb + hrow * 128;
                 const int wr = sx * 64 + frow;
                 const int fswQ = (wr >> 1) & 7;
@@ -1333,7 +1347,7 @@ __global__ __launch_bounds__(512) void deconv_s2_halo_kernel(ConvArgs a, int tot
 #pragma unroll
                     for (int i = 0; i < 4; ++i) fw[kk][i] = ld16(bQ + i * 16 * 128 + (((fq + 4 * kk) ^ fswQ) << 4));
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) fp[kk][j] = ld16(bP + j * 16 * 128 + (((fq + 4 * kk) ^ fswP) << 4));
+                    for (int j = 0; j < 2; ++j) fp[kk][j] = ld16(bP + j * 16 * 128 + ((H3_ROT ? ((fq + 4 * kk + fswP) & 7) : ((fq + 4 * kk) ^ fswP)) << 4));
                 }
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
@@ -3164,6 +3178,9 @@ static int run_gemm(const sgg_conv_desc* d, ConvArgs a, void* ws, size_t ws_byte
 // swizzle (256-byte rows), the 128-byte halo rows use w9_xkey (below), conflict-free for any tap shift.
 // Pixel tiles are split over `splits` blocks per output tile; slabs are summed in fixed order by wgrad_reduce_kernel.
 // -------------------------------------------------------------------------------------------------
+#ifndef W9_ISSUER
+#define W9_ISSUER 0                                    // 1: waves 4-7 issue ALL DMAs of the next stage, their SIMD partners 0-3 go straight to their MFMAs
+#endif
 #define W9_TW 64
 #define W9_PITCH 72                                    // halo row pitch in pixels (66 used; multiple of 8 = one DMA)
 #define W9_XBYTES (4 * W9_PITCH * 128)
@@ -3215,7 +3232,8 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
     const char* const D2 = netb ? a.dy2b : a.dy2;
 
     const int tiles1 = X2 ? a.tiles >> 1 : a.tiles;      // tiles of the first (x, dy) pair
-    auto stage_tile = [&](int stg, int tt) {
+    // vw: the wave whose share of the DMAs is issued (W9_ISSUER: waves 4-7 issue their own and their SIMD partner's)
+    auto stage_tile = [&](int stg, int tt, int vw) {
         const bool second = tt >= tiles1;
         const int t = second ? tt - tiles1 : tt;
         const char* xs = second ? X2 : X1;
@@ -3228,7 +3246,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
         // dy: 32 wave-instructions of 4 pixels x 256 B; wave w issues 4w..4w+3
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int d = wave * 4 + i;
+            const int d = vw * 4 + i;
             const int px = d * 4 + (lane >> 4), pos = lane & 15;
             const int key = wg2_key<bf16>(px) & 15;
             const int trow = px >> 6, tcol = px & 63;
@@ -3238,7 +3256,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
         // x halo: 36 wave-instructions of 8 pixels x 128 B (row k = q / 9, column group q % 9); wave w issues w, w+8, ...
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            const int q = wave + 8 * i;
+            const int q = vw + 8 * i;
             if (q >= 36) break;
             const int k = q / 9, cg = q - 9 * k;
             const int hp = cg * 8 + (lane >> 3), pos = lane & 7;
@@ -3281,12 +3299,18 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
             xoff[cls][h] = L * 128 + (((col >> 3) ^ w9_xkey(bl + L)) << 4) + (col & 7) * 2;
         }
     }
-    if (t_beg < t_end) stage_tile(0, t_beg);
+    if (t_beg < t_end) stage_tile(0, t_beg, wave);
     SGG_WAIT_VM0();
     __builtin_amdgcn_s_barrier();
     for (int t = t_beg; t < t_end; ++t) {
         const int cur = (t - t_beg) & 1;
-        if (t + 1 < t_end) stage_tile(cur ^ 1, t + 1);
+        if (t + 1 < t_end) {
+            if (!W9_ISSUER) stage_tile(cur ^ 1, t + 1, wave);
+            else if (wave >= 4) {
+#pragma nounroll
+                for (int rep = 0; rep < 2; ++rep) stage_tile(cur ^ 1, t + 1, wave - 4 * rep);
+            }
+        }
         const char* bX = smem + cur * W9_STAGE;
         const char* bD = bX + W9_XBYTES;
         // lane-varying address parts are precomputed (xoff / doff); what changes per fragment is a compile-time constant

@@ -3061,6 +3061,11 @@ static int launch_glds_cfg(const ConvArgs& a, int64_t Mmax, int DC, int classes,
 // SGG_CONV_IMPL=reg selects the v1 register-staged kernels (kept for A/B runs); default = v2 direct-to-LDS
 static bool use_glds() { return sgg_config().glds != 0; }
 
+#ifndef GLDS_NS_256x128
+#define GLDS_NS_256x128 3                              // LDS stages of the 256x128 tile (48 KB each): its layers (c2 forward, d2 data gradient,
+                                                       // D.h1 forward) gather their pixel operand from HBM with 9 short K-tiles per block;
+                                                       // two tiles in flight instead of one: 96.8 -> 93.4 us (c2), 26.4 -> 25.3 us (D.h1)
+#endif
 template <typename T, int MODE>
 static int launch_gemm(const ConvArgs& a, hipStream_t s) {
     int DC, classes;
@@ -3104,7 +3109,7 @@ static int launch_gemm(const ConvArgs& a, hipStream_t s) {
             if (DC >= 256 && Mmax * ((DC + 255) / 256) >= 256 * 160)
                 return launch_glds_cfg<T, MODE, 256, 256, 2, 8, 128, 2>(a, Mmax, DC, classes, s);
             if (DC >= 128 && Mmax * ((DC + 127) / 128) >= 256 * 160)
-                return launch_glds_cfg<T, MODE, 256, 128, 4, 8, 128, 2>(a, Mmax, DC, classes, s);
+                return launch_glds_cfg<T, MODE, 256, 128, 4, 8, 128, GLDS_NS_256x128>(a, Mmax, DC, classes, s);
             // 128x128 with 8 waves (2 per SIMD, two blocks per CU): the 4-wave variant ran at one wave per SIMD with
             // nothing to cover its LDS latencies (D.h3 data gradient 86 -> 60 us, D.h2 forward 36 -> 23 us)
             if (DC >= 128) return launch_glds_cfg<T, MODE, 128, 128, 2, 8>(a, Mmax, DC, classes, s);
@@ -3178,9 +3183,6 @@ static int run_gemm(const sgg_conv_desc* d, ConvArgs a, void* ws, size_t ws_byte
 // swizzle (256-byte rows), the 128-byte halo rows use w9_xkey (below), conflict-free for any tap shift.
 // Pixel tiles are split over `splits` blocks per output tile; slabs are summed in fixed order by wgrad_reduce_kernel.
 // -------------------------------------------------------------------------------------------------
-#ifndef W9_ISSUER
-#define W9_ISSUER 0                                    // 1: waves 4-7 issue ALL DMAs of the next stage, their SIMD partners 0-3 go straight to their MFMAs
-#endif
 #define W9_TW 64
 #define W9_PITCH 72                                    // halo row pitch in pixels (66 used; multiple of 8 = one DMA)
 #define W9_XBYTES (4 * W9_PITCH * 128)
@@ -3232,8 +3234,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
     const char* const D2 = netb ? a.dy2b : a.dy2;
 
     const int tiles1 = X2 ? a.tiles >> 1 : a.tiles;      // tiles of the first (x, dy) pair
-    // vw: the wave whose share of the DMAs is issued (W9_ISSUER: waves 4-7 issue their own and their SIMD partner's)
-    auto stage_tile = [&](int stg, int tt, int vw) {
+    auto stage_tile = [&](int stg, int tt) {
         const bool second = tt >= tiles1;
         const int t = second ? tt - tiles1 : tt;
         const char* xs = second ? X2 : X1;
@@ -3246,7 +3247,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
         // dy: 32 wave-instructions of 4 pixels x 256 B; wave w issues 4w..4w+3
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int d = vw * 4 + i;
+            const int d = wave * 4 + i;
             const int px = d * 4 + (lane >> 4), pos = lane & 15;
             const int key = wg2_key<bf16>(px) & 15;
             const int trow = px >> 6, tcol = px & 63;
@@ -3256,7 +3257,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
         // x halo: 36 wave-instructions of 8 pixels x 128 B (row k = q / 9, column group q % 9); wave w issues w, w+8, ...
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            const int q = vw + 8 * i;
+            const int q = wave + 8 * i;
             if (q >= 36) break;
             const int k = q / 9, cg = q - 9 * k;
             const int hp = cg * 8 + (lane >> 3), pos = lane & 7;
@@ -3299,18 +3300,12 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
             xoff[cls][h] = L * 128 + (((col >> 3) ^ w9_xkey(bl + L)) << 4) + (col & 7) * 2;
         }
     }
-    if (t_beg < t_end) stage_tile(0, t_beg, wave);
+    if (t_beg < t_end) stage_tile(0, t_beg);
     SGG_WAIT_VM0();
     __builtin_amdgcn_s_barrier();
     for (int t = t_beg; t < t_end; ++t) {
         const int cur = (t - t_beg) & 1;
-        if (t + 1 < t_end) {
-            if (!W9_ISSUER) stage_tile(cur ^ 1, t + 1, wave);
-            else if (wave >= 4) {
-#pragma nounroll
-                for (int rep = 0; rep < 2; ++rep) stage_tile(cur ^ 1, t + 1, wave - 4 * rep);
-            }
-        }
+        if (t + 1 < t_end) stage_tile(cur ^ 1, t + 1);
         const char* bX = smem + cur * W9_STAGE;
         const char* bD = bX + W9_XBYTES;
         // lane-varying address parts are precomputed (xoff / doff); what changes per fragment is a compile-time constant

@@ -34,7 +34,7 @@ MUST_NOT_SPILL = [
     "conv_wgrad_glds_kernelIDF16bLb0E", "conv_wgrad_glds_kernelIDF16bLb1E",
     "conv_gemm_glds_kernelIDF16bLi0ELi256ELi256ELi2ELi8ELi128ELi2E",
     "conv_gemm_glds_kernelIDF16bLi1ELi256ELi256ELi2ELi8ELi128ELi2E",
-    "conv_gemm_glds_kernelIDF16bLi0ELi256ELi128ELi4ELi8ELi128ELi2E",
+    "conv_gemm_glds_kernelIDF16bLi0ELi256ELi128ELi4ELi8ELi128ELi3E",
 ]
 # small-tile configurations: only spills are checked
 NO_SPILL_ONLY = ["conv_gemm_glds_kernelIDF16bLi0ELi128ELi128ELi2ELi8ELi128ELi2E", "conv_gemm_glds_kernelIDF16bLi1ELi128ELi128ELi2ELi8ELi128ELi2E"]

@@ -161,6 +161,23 @@ int sgg_conv2d_bwd_weight_pair2(const sgg_conv_desc* d, const void* xa0, const v
                                 const void* xb0, const void* dyb0, const void* xb1, const void* dyb1, float* dwb,
                                 int Cr, int Kr, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- grouped launches: the same call site of TWO networks of one architecture in one call (the upstream cycle step runs
+ * G_A->B beside G_B->A and D_A beside D_B; module.py:219-318 built twice).  `d` describes ONE network's call (N images per
+ * network); x / y (dy / dx, addend) are the STACKED tensors of 2N images, the first network's images first; (w, bias) belong to
+ * the first network, (w2, bias2) to the second.  The result is bit for bit that of two single calls -- each group runs the
+ * single call's tiles and split-K -- but in ONE launch for the generic GEMM and the stacked-batch halo kernels (two half-size
+ * launches of the discriminators' small maps are latency bound); the special 7x7 / narrow kernels run as two launches.
+ * ws >= 2 x the single call's workspace.  (3x3 stride-1 shapes with the norm-statistics epilogue or REFLECT fold:
+ * sgg_conv2d_fwd_stats_pair / sgg_conv2d_bwd_data_pair.) */
+int sgg_conv2d_fwd_group2(const sgg_conv_desc* d, const void* x, const void* w, const float* bias, const void* w2,
+                          const float* bias2, void* y, int act, float leak, void* ws, size_t ws_bytes, void* stream);
+int sgg_conv2d_bwd_data_group2(const sgg_conv_desc* d, const void* dy, const void* w, const void* w2, const void* addend,
+                               void* dx, void* ws, size_t ws_bytes, void* stream);
+int sgg_deconv2d_fwd_group2(const sgg_conv_desc* d, const void* x, const void* w_dgrad, const float* bias, const void* w_dgrad2,
+                            const float* bias2, void* y, int act, float leak, void* ws, size_t ws_bytes, void* stream);
+int sgg_deconv2d_bwd_data_group2(const sgg_conv_desc* d, const void* dy, const void* w_fwd, const void* w_fwd2, void* dx,
+                                 void* ws, size_t ws_bytes, void* stream);
+
 /* ---- deconv2d: tf.keras.layers.Conv2DTranspose(3x3, s2, 'same') ---- module.py:254,258
  * `d` describes the EQUIVALENT FORWARD CONV whose input is the deconv OUTPUT:
  *   (d->N,H,W,C) = deconv output, (d->Ho,Wo,K) = deconv input, pad_t/pad_l = TF SAME leading pads of that conv.

@@ -57,6 +57,10 @@ SIGNATURES = {
     "sgg_conv2d_pair_supported": (_i, [_dp]),
     "sgg_conv2d_fwd_stats_pair": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "sgg_conv2d_bwd_data_pair": (_i, [_dp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "sgg_conv2d_fwd_group2": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _sz, _vp]),
+    "sgg_conv2d_bwd_data_group2": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgg_deconv2d_fwd_group2": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _sz, _vp]),
+    "sgg_deconv2d_bwd_data_group2": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgg_conv2d_bwd_weight_workspace": (_sz, [_dp]),
     "sgg_conv2d_bwd_weight": (_i, [_dp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sgg_conv2d_bwd_weight_pair_supported": (_i, [_dp]),

@@ -52,6 +52,11 @@ struct ConvArgs {
     const char* wmat2;   // halo 3x3 kernels, two networks on one stacked batch: images >= nsplit use wmat2 / bias2
     const float* bias2;
     int nsplit;          //   (INT_MAX: one network)
+    // Generic GEMM kernel, GROUPED launch of two networks' call sites of one shape (sgg_*_group2): grp = 2 doubles the grid's z
+    // dimension; the second group reads / writes at these byte offsets from the pointers above and uses wmat2 / bias2.  Each
+    // group is exactly the single-network launch (same tiles, same split-K), so results are bit-identical to two launches.
+    int grp;
+    size_t net_src, net_dst, net_add, net_part;
     int dst_f32;         // halo 3x3 data gradient, mixed mode: dst is f32 (the gradient chain between instance norms keeps f32)
     int addend_f32;      //   ... and so is the addend
     int ablate;          // lab build only (SGG_ABLATE; always 0 and compiled out otherwise): 1 no in-loop DMA, 2 no LDS reads/MFMAs, 3 = 1 + no barrier,
@@ -394,7 +399,16 @@ __device__ unsigned long long g_dbg_clk[4];
 __device__ unsigned long long g_dbg_phase[8][16][6];
 
 template <typename T, int MODE, int BM, int BN, int WGM, int NW, int BKB, int NS>
-__global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
+__global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a_in) {
+    // grouped launch (a.grp == 2): blockIdx.z = group * classes + parity class; group 1 is the second network's call
+    ConvArgs a = a_in;
+    const int zclasses = (MODE == MODE_DGRAD) ? a.stride * a.stride : 1;
+    const int zgrp = (int)blockIdx.z / zclasses, zcls = (int)blockIdx.z - zgrp * zclasses;
+    if (zgrp) {
+        a.src += a.net_src; a.dst += a.net_dst; a.wmat = a.wmat2; a.bias = a.bias2;
+        if (a.addend) a.addend += a.net_add;
+        if (a.partial) a.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(a.partial) + a.net_part);
+    }
     constexpr int VEC = ET<T>::VEC;
     constexpr int ES = (int)sizeof(T);
     constexpr int WGN = NW / WGM;
@@ -419,8 +433,8 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar
     const int wm = wave / WGN, wn = wave % WGN;
     const int st = (MODE == MODE_DGRAD) ? a.stride : 1;
-    const int ph = (MODE == MODE_DGRAD) ? (int)blockIdx.z / a.stride : 0;
-    const int pw = (MODE == MODE_DGRAD) ? (int)blockIdx.z % a.stride : 0;
+    const int ph = (MODE == MODE_DGRAD) ? zcls / a.stride : 0;
+    const int pw = (MODE == MODE_DGRAD) ? zcls % a.stride : 0;
     const int nr = ph < a.R ? (a.R - ph + st - 1) / st : 0;
     const int ns = pw < a.S ? (a.S - pw + st - 1) / st : 0;
     const int SC = (MODE == MODE_FWD) ? a.C : a.K;
@@ -1293,7 +1307,8 @@ __global__ __launch_bounds__(512) void deconv_s2_halo_kernel(ConvArgs a, int tot
             const int q = wave * 3 + it;                // 0..23: tap column s = q / 8, rows 8*(q%8)..
             const int sx = q >> 3, row = (q & 7) * 8 + hsub;
             const int key = (((sx * 64 + row) >> 1) & 7);
-            const char* src = a.wmat + ((size_t)(T.n0 + row) * wrow + (size_t)(r * 3 + sx) * SC + chunk * 64) * 2 + ((hpos ^ key) << 4);
+            const char* wm = T.img >= a.nsplit ? a.wmat2 : a.wmat;      // stacked batch of two networks: per-image weights
+            const char* src = wm + ((size_t)(T.n0 + row) * wrow + (size_t)(r * 3 + sx) * SC + chunk * 64) * 2 + ((hpos ^ key) << 4);
             dma16_to_lds(src, (__attribute__((address_space(3))) void*)(dstb + q * 1024));
         }
     };
@@ -1365,10 +1380,11 @@ __global__ __launch_bounds__(512) void deconv_s2_halo_kernel(ConvArgs a, int tot
         if (last_chunk) {
             // epilogue of tile `cur`; the stores drain while the next tile is multiplied
             float bv[4][4];
+            const float* const bias_t = cur.img >= a.nsplit ? a.bias2 : a.bias;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bv[i][e] = a.bias ? a.bias[cur.n0 + i * 16 + fq * 4 + e] : 0.f;
+                for (int e = 0; e < 4; ++e) bv[i][e] = bias_t ? bias_t[cur.n0 + i * 16 + fq * 4 + e] : 0.f;
             act_dispatch(a.act, [&](auto act_c) {
                 constexpr int ACT = decltype(act_c)::value;
                 auto store_tile = [&](auto add_c) {
@@ -2990,6 +3006,7 @@ static bool desc_ok(const sgg_conv_desc* d) {
 static ConvArgs make_args(const sgg_conv_desc* d, const void* src, const void* w, const float* bias, void* dst, int act, float leak) {
     ConvArgs a;
     a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst; a.addend = nullptr; a.fold = nullptr; a.stats = nullptr; a.nx = nullptr; a.nstats = nullptr; a.ngamma = nullptr; a.nbeta = nullptr; a.nact = 0; a.nleak = 0.f; a.partial = nullptr; a.ksplit = 1; a.pdst = 0; a.dst_f32 = 0; a.addend_f32 = 0; a.wmat2 = nullptr; a.bias2 = nullptr; a.nsplit = 0x7fffffff;
+    a.grp = 1; a.net_src = a.net_dst = a.net_add = a.net_part = 0;
     a.ablate = sgg_config().ablate;
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S; a.stride = d->stride;
     a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.reflect = d->pad_mode == SGG_PAD_REFLECT;
@@ -3008,9 +3025,15 @@ static int launch_gemm_cfg(const ConvArgs& a, int64_t Mmax, int DC, int classes,
 }
 
 // out[p][c] = act(sum_s partial[s][p][c] + bias[c])  (fixed order -> deterministic)
+struct SplitKGroup { const float* bias2; size_t net_part, net_dst, net_add; };   // second group of a grouped launch (blockIdx.y == 1)
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* partial, const float* bias, const char* addend, char* out, int64_t nvec4,
-                                                            int DC, int ksplit, size_t slab, int act, float leak) {
+                                                            int DC, int ksplit, size_t slab, int act, float leak, SplitKGroup g2) {
+    if (blockIdx.y) {
+        partial = reinterpret_cast<const float*>(reinterpret_cast<const char*>(partial) + g2.net_part);
+        bias = g2.bias2; out += g2.net_dst;
+        if (addend) addend += g2.net_add;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec4; i += (int64_t)gridDim.x * blockDim.x) {
         f32x4 s4 = *reinterpret_cast<const f32x4*>(partial + i * 4);
         for (int sp = 1; sp < ksplit; ++sp) s4 += *reinterpret_cast<const f32x4*>(partial + sp * slab + i * 4);
@@ -3053,7 +3076,7 @@ static int launch_glds_cfg(const ConvArgs& a, int64_t Mmax, int DC, int classes,
     SGG_LDS_ATTR(kern, (int)lds);
     const int64_t tilesN = (DC + BN - 1) / BN;
     int64_t blocks = (Mmax + BM - 1) / BM * tilesN;
-    dim3 grid((unsigned)blocks, (unsigned)a.ksplit, (unsigned)classes);
+    dim3 grid((unsigned)blocks, (unsigned)a.ksplit, (unsigned)(classes * a.grp));
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
     return sgg_check_launch();
 }
@@ -3079,6 +3102,15 @@ static int launch_gemm(const ConvArgs& a, hipStream_t s) {
     } else {
         DC = a.C; classes = a.stride * a.stride;
         Mmax = (int64_t)a.N * ((a.H + a.stride - 1) / a.stride) * ((a.W + a.stride - 1) / a.stride);
+    }
+    if constexpr (MODE != MODE_BORDER && sizeof(T) == 2) {
+        // grouped launch of a shape whose kernel takes a STACKED batch with per-image weights (the LDS-resident 3x3 / stride-2
+        // halo kernels): the two groups are contiguous, so it is that kernel on 2N images with the split at N
+        if (a.grp == 2 && a.ksplit == 1 && (halo3_ok(a, MODE, true) || (MODE == MODE_DGRAD && s2halo_ok(a, true)))) {
+            ConvArgs b = a;
+            b.N = 2 * a.N; b.nsplit = a.N; b.grp = 1;
+            return launch_gemm<T, MODE>(b, s);
+        }
     }
     if constexpr (MODE == MODE_DGRAD && sizeof(T) == 2) {
         if (s2halo_ok(a, true)) return launch_s2halo(a, s);
@@ -3158,15 +3190,15 @@ template <typename T, int MODE>
 static int run_gemm(const sgg_conv_desc* d, ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
     GemmPlan g = plan_gemm(d, MODE);
     if (g.ksplit > 1) {
-        if (!ws || ws_bytes < g.ws_bytes) return SGG_EWORKSPACE;
-        a.ksplit = g.ksplit; a.partial = (float*)ws; a.pdst = g.pdst;
+        if (!ws || ws_bytes < g.ws_bytes * a.grp) return SGG_EWORKSPACE;
+        a.ksplit = g.ksplit; a.partial = (float*)ws; a.pdst = g.pdst; a.net_part = g.ws_bytes;
     }
     int rc = launch_gemm<T, MODE>(a, s);
     if (rc || g.ksplit <= 1) return rc;
     int64_t nvec4 = (int64_t)g.pdst * g.DC / 4;
     int blocks = (int)((nvec4 + 255) / 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, s, (const float*)ws, a.bias, a.addend, a.dst, nvec4, g.DC, g.ksplit,
-                       g.pdst * g.DC, a.act, a.leak);
+    hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks, a.grp), dim3(256), 0, s, (const float*)ws, a.bias, a.addend, a.dst, nvec4, g.DC, g.ksplit,
+                       g.pdst * g.DC, a.act, a.leak, SplitKGroup{a.bias2, a.net_part, a.net_dst, a.net_add});
     return sgg_check_launch();
 }
 
@@ -3914,6 +3946,69 @@ int sgg_conv2d_bwd_data_pair(const sgg_conv_desc* d, const void* dy, const void*
     NormBwdStats flags{};
     flags.w2 = w2; flags.nsplit = nsplit;
     return conv2d_bwd_data_impl(d, dy, w, addend, dx, &flags, ws, ws_bytes, stream);
+}
+
+// ---- grouped launches: the same call site of TWO networks of one architecture (G_A->B beside G_B->A, D_A beside D_B).  `d`
+// describes ONE network's call (N images); x / y (dy / dx, addend) hold 2N images, the first network's first; the result is
+// exactly that of two single calls (bit for bit: each group runs the single call's tiles and split-K), in ONE launch for the
+// generic GEMM and the stacked-batch halo kernels -- two half-size launches of the discriminators' small maps are latency
+// bound -- and as two launches for the special 7x7 / narrow kernels.  ws >= 2 x the single call's workspace.
+static inline size_t tensor_bytes(const sgg_conv_desc* d, bool out_side) {
+    const size_t es = d->dtype == SGG_BF16 ? 2 : 4;
+    return out_side ? (size_t)d->N * d->Ho * d->Wo * d->K * es : (size_t)d->N * d->H * d->W * d->C * es;
+}
+int sgg_conv2d_fwd_group2(const sgg_conv_desc* d, const void* x, const void* w, const float* bias, const void* w2, const float* bias2,
+                          void* y, int act, float leak, void* ws, size_t ws_bytes, void* stream) {
+    if (!desc_ok(d) || !x || !w || !w2 || !y) return SGG_EINVAL;
+    const size_t xin = tensor_bytes(d, false), yout = tensor_bytes(d, true);
+    if (!use_glds() || halo_narrow_in_ok(d, d->C, d->K) || n7_fwd_ok(d) || halo_fwd_ok(d)) {
+        int rc = sgg_conv2d_fwd(d, x, w, bias, y, act, leak, ws, ws_bytes, stream);
+        return rc ? rc : sgg_conv2d_fwd(d, (const char*)x + xin, w2, bias2, (char*)y + yout, act, leak, ws, ws_bytes, stream);
+    }
+    ConvArgs a = make_args(d, x, w, bias, y, act, leak);
+    a.grp = 2; a.wmat2 = (const char*)w2; a.bias2 = bias2; a.net_src = xin; a.net_dst = yout;
+    return d->dtype == SGG_BF16 ? run_gemm<bf16, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream)
+                                : run_gemm<float, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream);
+}
+int sgg_conv2d_bwd_data_group2(const sgg_conv_desc* d, const void* dy, const void* w, const void* w2, const void* addend, void* dx,
+                               void* ws, size_t ws_bytes, void* stream) {
+    if (!desc_ok(d) || !dy || !w || !w2 || !dx) return SGG_EINVAL;
+    const size_t xin = tensor_bytes(d, false), yout = tensor_bytes(d, true);
+    const bool special = !use_glds() || (!addend && (halo_narrow_in_ok(d, d->K, d->C) || n7_dgrad_ok(d) || halo_dgrad_narrow_ok(d))) || fold_bytes(d) > 0;
+    if (special) {                                       // (REFLECT shapes of the 3x3 halo kernel: sgg_conv2d_bwd_data_pair)
+        int rc = sgg_conv2d_bwd_data(d, dy, w, addend, dx, ws, ws_bytes, stream);
+        return rc ? rc : sgg_conv2d_bwd_data(d, (const char*)dy + yout, w2, addend ? (const char*)addend + xin : nullptr, (char*)dx + xin, ws, ws_bytes, stream);
+    }
+    ConvArgs a = make_args(d, dy, w, nullptr, dx, SGG_ACT_NONE, 0.f);
+    a.addend = (const char*)addend;
+    a.grp = 2; a.wmat2 = (const char*)w2; a.net_src = yout; a.net_dst = xin; a.net_add = xin;
+    return d->dtype == SGG_BF16 ? run_gemm<bf16, MODE_DGRAD>(d, a, ws, ws_bytes, (hipStream_t)stream)
+                                : run_gemm<float, MODE_DGRAD>(d, a, ws, ws_bytes, (hipStream_t)stream);
+}
+// Conv2DTranspose: `d` is the equivalent forward conv of ONE network (sgg_deconv2d_fwd); x: (2N,Ho,Wo,K), y: (2N,H,W,C)
+int sgg_deconv2d_fwd_group2(const sgg_conv_desc* d, const void* x, const void* w, const float* bias, const void* w2, const float* bias2,
+                            void* y, int act, float leak, void* ws, size_t ws_bytes, void* stream) {
+    if (!desc_ok(d) || d->pad_mode != SGG_PAD_ZERO || !x || !w || !w2 || !y) return SGG_EINVAL;
+    ConvArgs a = make_args(d, x, w, bias, y, act, leak);
+    if (!use_glds()) {
+        int rc = sgg_deconv2d_fwd(d, x, w, bias, y, act, leak, ws, ws_bytes, stream);
+        return rc ? rc : sgg_deconv2d_fwd(d, (const char*)x + tensor_bytes(d, true), w2, bias2, (char*)y + tensor_bytes(d, false), act, leak, ws, ws_bytes, stream);
+    }
+    a.grp = 2; a.wmat2 = (const char*)w2; a.bias2 = bias2; a.net_src = tensor_bytes(d, true); a.net_dst = tensor_bytes(d, false);
+    return d->dtype == SGG_BF16 ? run_gemm<bf16, MODE_DGRAD>(d, a, ws, ws_bytes, (hipStream_t)stream)
+                                : run_gemm<float, MODE_DGRAD>(d, a, ws, ws_bytes, (hipStream_t)stream);
+}
+int sgg_deconv2d_bwd_data_group2(const sgg_conv_desc* d, const void* dy, const void* w, const void* w2, void* dx,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    if (!desc_ok(d) || d->pad_mode != SGG_PAD_ZERO || !dy || !w || !w2 || !dx) return SGG_EINVAL;
+    if (!use_glds()) {
+        int rc = sgg_deconv2d_bwd_data(d, dy, w, dx, ws, ws_bytes, stream);
+        return rc ? rc : sgg_deconv2d_bwd_data(d, (const char*)dy + tensor_bytes(d, false), w2, (char*)dx + tensor_bytes(d, true), ws, ws_bytes, stream);
+    }
+    ConvArgs a = make_args(d, dy, w, nullptr, dx, SGG_ACT_NONE, 0.f);
+    a.grp = 2; a.wmat2 = (const char*)w2; a.net_src = tensor_bytes(d, false); a.net_dst = tensor_bytes(d, true);
+    return d->dtype == SGG_BF16 ? run_gemm<bf16, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream)
+                                : run_gemm<float, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream);
 }
 
 size_t sgg_conv2d_bwd_weight_workspace(const sgg_conv_desc* d) {

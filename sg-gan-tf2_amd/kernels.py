@@ -329,6 +329,49 @@ def conv_wgrad_pair2(g: ConvGeom, net_a, net_b, accumulate=False):
     return True
 
 
+# ---- grouped launches (sgg_*_group2): the same call site of two networks in one call.  `g` is ONE network's geometry; the tensors
+# hold 2N images, the first network's first.  Bit-identical to two single calls.
+def _stacked(shape):
+    return (2 * shape[0],) + tuple(shape[1:])
+
+
+def conv_fwd_group2(g: ConvGeom, x, w_fwd, bias, w_fwd2, bias2, act=A.ACT_NONE, leak=0.0):
+    assert tuple(x.shape) == _stacked(g.x_shape) and not g.is_deconv
+    y = torch.empty(_stacked(g.y_shape), dtype=x.dtype, device=x.device)
+    ws = workspace(2 * g.ws_fwd, x.device) if g.ws_fwd else None
+    A.check(A.lib().sgg_conv2d_fwd_group2(C.byref(g.desc), _p(x), _p(w_fwd), _p(bias), _p(w_fwd2), _p(bias2), _p(y), act, leak,
+                                          _p(ws), 2 * g.ws_fwd, _s()), "conv2d_fwd_group2")
+    return y
+
+
+def conv_dgrad_group2(g: ConvGeom, dy, w_dgrad, w_dgrad2, addend=None):
+    assert tuple(dy.shape) == _stacked(g.y_shape) and not g.is_deconv
+    assert addend is None or (tuple(addend.shape) == _stacked(g.x_shape) and addend.dtype == dy.dtype)
+    dx = torch.empty(_stacked(g.x_shape), dtype=dy.dtype, device=dy.device)
+    ws = workspace(2 * g.ws_dgrad, dy.device) if g.ws_dgrad else None
+    A.check(A.lib().sgg_conv2d_bwd_data_group2(C.byref(g.desc), _p(dy), _p(w_dgrad), _p(w_dgrad2), _p(addend), _p(dx),
+                                               _p(ws), 2 * g.ws_dgrad, _s()), "conv2d_bwd_data_group2")
+    return dx
+
+
+def deconv_fwd_group2(g: ConvGeom, x, w_dgrad, bias, w_dgrad2, bias2, act=A.ACT_NONE, leak=0.0):
+    assert tuple(x.shape) == _stacked(g.x_shape) and g.is_deconv
+    y = torch.empty(_stacked(g.y_shape), dtype=x.dtype, device=x.device)
+    ws = workspace(2 * g.ws_fwd, x.device) if g.ws_fwd else None
+    A.check(A.lib().sgg_deconv2d_fwd_group2(C.byref(g.desc), _p(x), _p(w_dgrad), _p(bias), _p(w_dgrad2), _p(bias2), _p(y), act, leak,
+                                            _p(ws), 2 * g.ws_fwd, _s()), "deconv2d_fwd_group2")
+    return y
+
+
+def deconv_dgrad_group2(g: ConvGeom, dy, w_fwd, w_fwd2):
+    assert tuple(dy.shape) == _stacked(g.y_shape) and g.is_deconv
+    dx = torch.empty(_stacked(g.x_shape), dtype=dy.dtype, device=dy.device)
+    ws = workspace(2 * g.ws_dgrad, dy.device) if g.ws_dgrad else None
+    A.check(A.lib().sgg_deconv2d_bwd_data_group2(C.byref(g.desc), _p(dy), _p(w_fwd), _p(w_fwd2), _p(dx), _p(ws), 2 * g.ws_dgrad, _s()),
+            "deconv2d_bwd_data_group2")
+    return dx
+
+
 def deconv_fwd(g: ConvGeom, x, w_dgrad, bias, act=A.ACT_NONE, leak=0.0, out=None):
     assert tuple(x.shape) == g.x_shape and g.is_deconv
     y = _out(out, g.y_shape, x.dtype, x.device)

@@ -30,7 +30,7 @@ def default_args(**over):
              segment_class=34, beta1=0.5, lr=0.0002, L1_lambda=10.0, Lg_lambda=5.0, use_resnet=True, use_pix2pix=False,
              use_lsgan=True, ratio_gan2seg=10, max_size=50, phase="train", dataset_dir="city",
              dtype="bf16", device="cuda", n_blocks=9, seed=19, graph=False, mixed=False, paired=True,
-             fuse_in_stats=True, fuse_in_bwd=False, g_buckets=3, keep_tapes=False)
+             fuse_in_stats=True, fuse_in_bwd=False, g_buckets=3, keep_tapes=False, group2=True)
     a.update(over)
     return SimpleNamespace(**a)
 
@@ -103,6 +103,7 @@ class sggan(object):
             net.mixed = self.mixed
             # conv epilogue -> norm statistics (on), data-gradient epilogue -> norm-backward sums (opt-in; module.py)
             net.fuse_in_stats, net.fuse_in_bwd = bool(g("fuse_in_stats", True)), bool(g("fuse_in_bwd", False))
+            net.group2 = bool(g("group2", True))
         # data parallel: each generator's gradient buffer is exchanged as this many contiguous layer-group buckets, launched
         # in backward-completion order so that all but the last overlap the rest of the backward pass
         self.g_buckets = max(1, int(g("g_buckets", 3)))

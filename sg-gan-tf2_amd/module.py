@@ -385,6 +385,7 @@ class _Net:
         # kernel supports it (the residual chain) -- see sgg_conv2d_bwd_data_mixed in include/sggan.h
         self.mixed = False
         self.fuse_in_stats, self.fuse_in_bwd = FUSE_CONV_IN_STATS, FUSE_CONV_IN_BWD
+        self.group2 = True           # lockstep pairs: both networks' generic convolutions in one grouped launch (sgg_*_group2)
         self._pack_tables = {}
 
     def conv_units(self):
@@ -613,8 +614,8 @@ class _PairUnit:
             y, stats = K.instnorm_fwd_partial_pair(xc, part, PA.p(na + "_g"), PA.p(na + "_beta"), PB.p(nb + "_g"), PB.p(nb + "_beta"), n,
                                                    residual, ua.net.eps, ua.act, ua.leak)
             return y, (g, x, xc, stats)
-        xc = torch.empty((2 * n,) + tuple(g.y_shape[1:]), dtype=x.dtype, device=x.device)
         if ua.kind == "conv" and ua.norm and g.stats_chunks and ua.net.fuse_in_stats:
+            xc = torch.empty((2 * n,) + tuple(g.y_shape[1:]), dtype=x.dtype, device=x.device)
             part = torch.empty((2 * n, g.stats_chunks, g.y_shape[3], 2), dtype=torch.float32, device=x.device)
             for u, sl in halves:
                 wf, _ = u.packed(x.dtype)
@@ -622,12 +623,21 @@ class _PairUnit:
             y, stats = K.instnorm_fwd_partial_pair(xc, part, PA.p(na + "_g"), PA.p(na + "_beta"), PB.p(nb + "_g"), PB.p(nb + "_beta"), n,
                                                    residual, ua.net.eps, ua.act, ua.leak)
             return y, (g, x, xc, stats)
-        for u, sl in halves:
-            wf, wd = u.packed(x.dtype)
-            if u.kind == "conv":
-                K.conv_fwd(g, x[sl], wf, u.net.P.p(u.name + "_b"), fused_act, u.leak, out=xc[sl])
-            else:
-                K.deconv_fwd(g, x[sl], wd, u.net.P.p(u.name + "_b"), fused_act, u.leak, out=xc[sl])
+        # every other convolution: ONE grouped launch for both networks (sgg_*_group2: each network's call as its own group of
+        # blocks -- bit-identical to two calls; the discriminators' small maps are latency bound, two half-size launches cost twice)
+        wfa, wda = ua.packed(x.dtype)
+        wfb, wdb = ub.packed(x.dtype)
+        if not ua.net.group2:                                 # A/B switch: one launch per network into slices of the stacked output
+            xc = torch.empty((2 * n,) + tuple(g.y_shape[1:]), dtype=x.dtype, device=x.device)
+            for u, sl, wf, wd in ((ua, halves[0][1], wfa, wda), (ub, halves[1][1], wfb, wdb)):
+                if u.kind == "conv":
+                    K.conv_fwd(g, x[sl], wf, u.net.P.p(u.name + "_b"), fused_act, u.leak, out=xc[sl])
+                else:
+                    K.deconv_fwd(g, x[sl], wd, u.net.P.p(u.name + "_b"), fused_act, u.leak, out=xc[sl])
+        elif ua.kind == "conv":
+            xc = K.conv_fwd_group2(g, x, wfa, PA.p(na + "_b"), wfb, PB.p(nb + "_b"), fused_act, ua.leak)
+        else:
+            xc = K.deconv_fwd_group2(g, x, wda, PA.p(na + "_b"), wdb, PB.p(nb + "_b"), fused_act, ua.leak)
         if not ua.norm:
             return xc, (g, x, xc, None)
         y, stats = K.instnorm_fwd_pair(xc, PA.p(na + "_g"), PA.p(na + "_beta"), PB.p(nb + "_g"), PB.p(nb + "_beta"), n,
@@ -670,16 +680,20 @@ class _PairUnit:
             return None
         if ua.kind == "conv" and ua.geom(x).pair_ok:
             return K.conv_dgrad_pair(ua.geom(x), dxc, ua.packed(x.dtype)[1], ub.packed(x.dtype)[1], n, addend)
-        dx = torch.empty((2 * n,) + tuple(g.x_shape[1:]), dtype=dxc.dtype, device=dxc.device)
-        for u, sl in halves:
-            wf, wd = u.packed(x.dtype)
-            if u.kind == "conv":
-                K.conv_dgrad(g, dxc[sl], wd, None if addend is None else addend[sl], out=dx[sl])
-            else:
-                K.deconv_dgrad(g, dxc[sl], wf, out=dx[sl])
-        if ua.kind != "conv" and addend is not None:
-            dx = K.add(dx, addend)
-        return dx
+        wfa, wda = ua.packed(x.dtype)
+        wfb, wdb = ub.packed(x.dtype)
+        if not ua.net.group2:
+            dx = torch.empty((2 * n,) + tuple(g.x_shape[1:]), dtype=dxc.dtype, device=dxc.device)
+            for u, sl, wf, wd in ((ua, halves[0][1], wfa, wda), (ub, halves[1][1], wfb, wdb)):
+                if u.kind == "conv":
+                    K.conv_dgrad(g, dxc[sl], wd, None if addend is None else addend[sl], out=dx[sl])
+                else:
+                    K.deconv_dgrad(g, dxc[sl], wf, out=dx[sl])
+            return dx if (ua.kind == "conv" or addend is None) else K.add(dx, addend)
+        if ua.kind == "conv":
+            return K.conv_dgrad_group2(g, dxc, wda, wdb, addend)
+        dx = K.deconv_dgrad_group2(g, dxc, wfa, wfb)
+        return dx if addend is None else K.add(dx, addend)
 
 
 class GeneratorPair:

@@ -500,3 +500,49 @@ def test_timed_launch_hooks_put_events_on_the_kernel_dispatch(sg):
     y2 = K.conv_fwd(g, x, wf, None)                                                      # and the disarmed launch is an ordinary one
     assert torch.equal(y, y2)
     A.lib().sgg_event_destroy(s); A.lib().sgg_event_destroy(e)
+
+
+@pytest.mark.parametrize("cfg", [
+    # (N per network, H, W, C, K, R, stride, padding, dtype)
+    ("D.h32-like: split-K tail", 2, 15, 31, 512, 512, 3, 2, "VALID", torch.bfloat16),
+    ("D.h4-like: 34 output channels", 2, 5, 13, 512, 40, 3, 1, "SAME", torch.bfloat16),
+    ("c2-like: stride-2 forward / stride-2 halo data gradient", 2, 64, 128, 64, 128, 3, 2, "SAME", torch.bfloat16),
+    ("h3-like: 256x256 tiles", 2, 32, 64, 256, 512, 3, 1, "SAME", torch.bfloat16),
+    ("odd generic f32", 3, 9, 11, 16, 24, 3, 1, "SAME", torch.float32),
+    ("3x3 stride-1 halo shape, zero padding", 2, 64, 128, 64, 64, 3, 1, "SAME", torch.bfloat16),
+], ids=lambda c: c[0].split(":")[0])
+def test_group2_launches_equal_two_single_calls(sg, cfg):
+    """sgg_conv2d_fwd_group2 / _bwd_data_group2 / sgg_deconv2d_*_group2: the same call site of two networks in one call must be
+    BIT-IDENTICAL to two single calls (each group runs the single call's tiles and split-K), with and without the fused
+    activation / bias / skip-gradient addend -- the lockstep pairs of the cycle step rely on it."""
+    from sggan_amd import kernels as K
+    from sggan_amd import _abi as A
+    _, N, H, W, Ci, Co, R, stride, padding, dt = cfg
+    g = K.conv_geom(N, H, W, Ci, Co, R, R, stride, padding, 0, dt)
+    gen = torch.Generator().manual_seed(3)
+    r = lambda *sh: torch.randn(sh, generator=gen).cuda()
+    x = r(2 * N, H, W, Ci).to(dt)
+    dy = r(*((2 * N,) + tuple(g.y_shape[1:]))).to(dt)
+    add = r(2 * N, H, W, Ci).to(dt)
+    ws_ = [K.pack_weights(r(R, R, Ci, Co) / (R * R * Ci) ** 0.5, Ci, Co, dt) for _ in range(2)]
+    bs = [r(Co), r(Co)]
+    for act in (A.ACT_NONE, A.ACT_LRELU):
+        y2 = K.conv_fwd_group2(g, x, ws_[0][0], bs[0], ws_[1][0], bs[1], act, 0.3)
+        for k in range(2):
+            assert torch.equal(y2[k * N:(k + 1) * N], K.conv_fwd(g, x[k * N:(k + 1) * N], ws_[k][0], bs[k], act, 0.3)), ("fwd", act, k)
+    for ad in (None, add):
+        dx2 = K.conv_dgrad_group2(g, dy, ws_[0][1], ws_[1][1], ad)
+        for k in range(2):
+            ref = K.conv_dgrad(g, dy[k * N:(k + 1) * N], ws_[k][1], None if ad is None else ad[k * N:(k + 1) * N])
+            assert torch.equal(dx2[k * N:(k + 1) * N], ref), ("dgrad", ad is not None, k)
+    if stride == 2 and padding == "SAME" and H % 2 == 0 and W % 2 == 0:
+        # the same weights as a Conv2DTranspose (module.py:254,258): x' = (2N, H/2, W/2, Co) -> (2N, H, W, Ci)
+        gd = K.deconv_geom(N, H // 2, W // 2, Co, Ci, R, R, 2, dt)
+        xt = r(2 * N, H // 2, W // 2, Co).to(dt)
+        bt = [r(Ci), r(Ci)]
+        yt = K.deconv_fwd_group2(gd, xt, ws_[0][1], bt[0], ws_[1][1], bt[1], A.ACT_RELU, 0.0)
+        dxt = K.deconv_dgrad_group2(gd, x, ws_[0][0], ws_[1][0])
+        for k in range(2):
+            sl = slice(k * N, (k + 1) * N)
+            assert torch.equal(yt[sl], K.deconv_fwd(gd, xt[sl], ws_[k][1], bt[k], A.ACT_RELU, 0.0)), ("deconv fwd", k)
+            assert torch.equal(dxt[sl], K.deconv_dgrad(gd, x[sl], ws_[k][0])), ("deconv dgrad", k)

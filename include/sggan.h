@@ -173,6 +173,12 @@ int sgg_conv2d_fwd_group2(const sgg_conv_desc* d, const void* x, const void* w, 
                           const float* bias2, void* y, int act, float leak, void* ws, size_t ws_bytes, void* stream);
 int sgg_conv2d_bwd_data_group2(const sgg_conv_desc* d, const void* dy, const void* w, const void* w2, const void* addend,
                                void* dx, void* ws, size_t ws_bytes, void* stream);
+/* weight gradients of the two networks: their main kernels run back to back into two sets of split slabs, ONE reduce launch sums
+ * both (each in the single call's order).  dw / dw2: the two networks' f32 gradients, layouts as sgg_conv2d_bwd_weight. */
+int sgg_conv2d_bwd_weight_group2(const sgg_conv_desc* d, const void* x, const void* dy, float* dw, float* dw2, int C_real, int K_real,
+                                 int accumulate, void* ws, size_t ws_bytes, void* stream);
+int sgg_deconv2d_bwd_weight_group2(const sgg_conv_desc* d, const void* x, const void* dy, float* dw, float* dw2, int C_real, int K_real,
+                                   int accumulate, void* ws, size_t ws_bytes, void* stream);
 int sgg_deconv2d_fwd_group2(const sgg_conv_desc* d, const void* x, const void* w_dgrad, const float* bias, const void* w_dgrad2,
                             const float* bias2, void* y, int act, float leak, void* ws, size_t ws_bytes, void* stream);
 int sgg_deconv2d_bwd_data_group2(const sgg_conv_desc* d, const void* dy, const void* w_fwd, const void* w_fwd2, void* dx,
@@ -196,6 +202,9 @@ int sgg_deconv2d_bwd_weight(const sgg_conv_desc* d, const void* x, const void* d
 size_t sgg_bias_grad_workspace(int64_t P, int C);
 int sgg_bias_grad(const void* dy, float* db, int64_t P, int C, int C_real, int accumulate, int dtype,
                   void* ws, size_t ws_bytes, void* stream);
+/* grouped call (see sgg_conv2d_fwd_group2): dy holds two networks' tensors back to back, P pixels each; ws >= 2 x the single call's */
+int sgg_bias_grad_group2(const void* dy, float* db, float* db2, int64_t P, int C, int C_real, int accumulate, int dtype,
+                         void* ws, size_t ws_bytes, void* stream);
 
 /* ---- instance_norm: tfa.layers.InstanceNormalization ---- module.py:212,216,233,...,308 (spec by name: ops.py:13-22)
  * y = act(gamma*(x-mean)*rstd + beta) (+ residual, added AFTER act; module.py:217 uses act NONE).

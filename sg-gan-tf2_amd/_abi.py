@@ -61,6 +61,8 @@ SIGNATURES = {
     "sgg_conv2d_bwd_data_group2": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgg_deconv2d_fwd_group2": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _sz, _vp]),
     "sgg_deconv2d_bwd_data_group2": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgg_conv2d_bwd_weight_group2": (_i, [_dp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sgg_deconv2d_bwd_weight_group2": (_i, [_dp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sgg_conv2d_bwd_weight_workspace": (_sz, [_dp]),
     "sgg_conv2d_bwd_weight": (_i, [_dp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sgg_conv2d_bwd_weight_pair_supported": (_i, [_dp]),
@@ -73,6 +75,7 @@ SIGNATURES = {
     "sgg_deconv2d_bwd_weight": (_i, [_dp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sgg_bias_grad_workspace": (_sz, [_i64, _i]),
     "sgg_bias_grad": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "sgg_bias_grad_group2": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sgg_instnorm_workspace": (_sz, [_i, _i64, _i]),
     "sgg_instnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _i, _f, _i, _vp, _sz, _vp]),
     "sgg_instnorm_fwd_partial": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _f, _i, _f, _i, _vp]),

@@ -3646,49 +3646,70 @@ static int run_w9(const sgg_conv_desc* d, const W9Net& na, const W9Net* nb, int 
 }
 
 template <typename T>
-static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, float* dw, int Cr, int Kr, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+// (xb, dyb, dwb): the same call site of a SECOND network (sgg_*_bwd_weight_group2): its main kernel runs right after the first one's
+// into the slabs behind them, and ONE reduce launch sums both sets (each in the single call's order: bit-identical results).
+static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, float* dw, int Cr, int Kr, int accumulate, void* ws, size_t ws_bytes, hipStream_t s,
+                     const void* xb = nullptr, const void* dyb = nullptr, float* dwb = nullptr) {
+    const int nets = xb ? 2 : 1;
     WgradArgs a;
     a.x = (const char*)x; a.dy = (const char*)dy; a.ws = (float*)ws;
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S; a.stride = d->stride;
     a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.reflect = d->pad_mode == SGG_PAD_REFLECT;
     a.P = d->N * d->Ho * d->Wo;
     if constexpr (sizeof(T) == 2) {                     // the two 7x7 layers with a 3-channel side
-        if (use_glds() && w7_head_ok(d)) return run_w7(d, false, x, dy, dw, Cr, Kr, accumulate, ws, ws_bytes, s);
-        if (use_glds() && w7_stem_ok(d)) return run_w7(d, true, x, dy, dw, Cr, Kr, accumulate, ws, ws_bytes, s);
+        if (use_glds() && (w7_head_ok(d) || w7_stem_ok(d))) {
+            const bool stem = !w7_head_ok(d);
+            int rc7 = run_w7(d, stem, x, dy, dw, Cr, Kr, accumulate, ws, ws_bytes, s);
+            return (rc7 || !xb) ? rc7 : run_w7(d, stem, xb, dyb, dwb, Cr, Kr, accumulate, ws, ws_bytes, s);
+        }
     }
     if (halo_wgrad_ok(d)) {
         const int nb = halo_wgrad_blocks(d), ntiles = d->N * (d->H / HALO_TH) * (d->W / HALO_TW);
         size_t need = (size_t)nb * d->R * d->S * d->C * d->K * sizeof(float);
-        if (ws_bytes < need || !ws) return SGG_EWORKSPACE;
+        if (ws_bytes < need * nets || !ws) return SGG_EWORKSPACE;
         a.pix_per_split = 0; a.dHW = make_fastdiv(1); a.dW = make_fastdiv(1);
         size_t lds = 512 * 16 * sizeof(T) + (size_t)(HALO_TH + d->R - 1) * (HALO_TW + d->S - 1) * 128 + 1024;
         auto kern = conv_halo_wgrad_kernel<T>;
         SGG_LDS_ATTR(kern, 160 * 1024);
         hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, s, a, ntiles);
+        if (xb) {
+            a.x = (const char*)xb; a.dy = (const char*)dyb; a.ws = (float*)((char*)ws + need);
+            hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, s, a, ntiles);
+        }
         int rc0 = sgg_check_launch();
         if (rc0) return rc0;
-        int64_t total0 = (int64_t)d->R * d->S * Cr * (d->K / 4);
+        int64_t total0 = (int64_t)d->R * d->S * Cr * (d->K / 4) * nets;
         int blocks0 = (int)((total0 + 255) / 256); if (blocks0 > 4096) blocks0 = 4096;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks0), dim3(256), 0, s, (const float*)ws, dw, d->R * d->S, d->C, d->K, Cr, Kr, nb, accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks0), dim3(256), 0, s, (const float*)ws, dw, d->R * d->S, d->C, d->K, Cr, Kr, nb, accumulate, dwb);
         return sgg_check_launch();
     }
     if constexpr (sizeof(T) == 2) {
-        if (w9_ok(d)) return run_w9(d, W9Net{x, dy, nullptr, nullptr, dw}, nullptr, Cr, Kr, accumulate, ws, ws_bytes, s);   // 3x3 s1: x halo resident, all taps per block
+        if (w9_ok(d)) {                                   // 3x3 s1: x halo resident, all taps per block
+            if (!xb) return run_w9(d, W9Net{x, dy, nullptr, nullptr, dw}, nullptr, Cr, Kr, accumulate, ws, ws_bytes, s);
+            // (two networks in one launch of this kernel halve the slabs per network -- another summation order than the single
+            // call's; a grouped call promises the single call's bits, so here it is two launches)
+            int rc9 = run_w9(d, W9Net{x, dy, nullptr, nullptr, dw}, nullptr, Cr, Kr, accumulate, ws, ws_bytes, s);
+            return rc9 ? rc9 : run_w9(d, W9Net{xb, dyb, nullptr, nullptr, dwb}, nullptr, Cr, Kr, accumulate, ws, ws_bytes, s);
+        }
         if (w9s_ok(d)) {                                  // 3x3 s2: the same with a parity-de-interleaved halo
             const int sp = w9s_splits(d);
             size_t need9 = (size_t)sp * 9 * d->C * d->K * sizeof(float);
-            if (ws_bytes < need9 || !ws) return SGG_EWORKSPACE;
+            if (ws_bytes < need9 * nets || !ws) return SGG_EWORKSPACE;
             W9SArgs w;
             w.x = (const char*)x; w.dy = (const char*)dy; w.ws = (float*)ws;
             w.N = d->N; w.H = d->H; w.W = d->W; w.C = d->C; w.K = d->K; w.Ho = d->Ho; w.Wo = d->Wo; w.pad_t = d->pad_t; w.pad_l = d->pad_l;
             w.tiles = w9s_tiles(d); w.tiles_per_split = (w.tiles + sp - 1) / sp;
             SGG_LDS_ATTR(conv3x3_wgrad_halo_s2_kernel, 2 * W9S_STAGE);
             hipLaunchKernelGGL(conv3x3_wgrad_halo_s2_kernel, dim3((unsigned)(sp * (d->C / 64) * (d->K / 128))), dim3(512), 2 * W9S_STAGE, s, w);
+            if (xb) {
+                w.x = (const char*)xb; w.dy = (const char*)dyb; w.ws = (float*)((char*)ws + need9);
+                hipLaunchKernelGGL(conv3x3_wgrad_halo_s2_kernel, dim3((unsigned)(sp * (d->C / 64) * (d->K / 128))), dim3(512), 2 * W9S_STAGE, s, w);
+            }
             int rc9 = sgg_check_launch();
             if (rc9) return rc9;
-            int64_t total9 = (int64_t)9 * Cr * (d->K / 4);
+            int64_t total9 = (int64_t)9 * Cr * (d->K / 4) * nets;
             int blocks9 = (int)((total9 + 255) / 256); if (blocks9 > 4096) blocks9 = 4096;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks9), dim3(256), 0, s, (const float*)ws, dw, 9, d->C, d->K, Cr, Kr, sp, accumulate);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks9), dim3(256), 0, s, (const float*)ws, dw, 9, d->C, d->K, Cr, Kr, sp, accumulate, dwb);
             return sgg_check_launch();
         }
     }
@@ -3697,8 +3718,10 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
     splits = (a.P + a.pix_per_split - 1) / a.pix_per_split;
     a.dHW = make_fastdiv((uint32_t)(d->Ho * d->Wo)); a.dW = make_fastdiv((uint32_t)d->Wo);
     size_t need = (size_t)splits * d->R * d->S * d->C * d->K * sizeof(float);
-    if (ws_bytes < need || !ws) return SGG_EWORKSPACE;
-    int rc;
+    if (ws_bytes < need * nets || !ws) return SGG_EWORKSPACE;
+    int rc = SGG_OK;
+    for (int net = 0; net < nets && rc == SGG_OK; ++net) {
+    if (net) { a.x = (const char*)xb; a.dy = (const char*)dyb; a.ws = (float*)((char*)ws + need); }
     if (wgrad_use_v2(d)) {
         constexpr size_t lds = 2 * 2 * (size_t)(sizeof(T) == 2 ? 64 : 32) * 256 * sizeof(T);
         SGG_LDS_ATTR((conv_wgrad_glds_kernel<T, false>), lds);
@@ -3712,10 +3735,11 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
     } else if (d->K >= 128) rc = launch_wgrad_cfg<T, 128, 128, 2>(a, splits, s);
     else if (d->K > 16) rc = launch_wgrad_cfg<T, 128, 64, 4>(a, splits, s);
     else rc = launch_wgrad_cfg<T, 128, 16, 4>(a, splits, s);
+    }
     if (rc) return rc;
-    int64_t total = (int64_t)d->R * d->S * Cr * (d->K / 4);
+    int64_t total = (int64_t)d->R * d->S * Cr * (d->K / 4) * nets;
     int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, dw, d->R * d->S, d->C, d->K, Cr, Kr, splits, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, dw, d->R * d->S, d->C, d->K, Cr, Kr, splits, accumulate, dwb);
     return sgg_check_launch();
 }
 
@@ -4026,6 +4050,16 @@ int sgg_conv2d_bwd_weight(const sgg_conv_desc* d, const void* x, const void* dy,
                                 : run_wgrad<float>(d, x, dy, dw, Cr, Kr, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
 
+// Grouped call (see sgg_conv2d_fwd_group2): x / dy hold 2N images, the first network's first; dw / dw2 are the two networks' gradients.
+int sgg_conv2d_bwd_weight_group2(const sgg_conv_desc* d, const void* x, const void* dy, float* dw, float* dw2, int Cr, int Kr, int accumulate,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    if (!desc_ok(d) || !x || !dy || !dw || !dw2 || Cr <= 0 || Kr <= 0 || Cr > d->C || Kr > d->K) return SGG_EINVAL;
+    const char* xb = (const char*)x + tensor_bytes(d, false);
+    const char* dyb = (const char*)dy + tensor_bytes(d, true);
+    return d->dtype == SGG_BF16 ? run_wgrad<bf16>(d, x, dy, dw, Cr, Kr, accumulate, ws, ws_bytes, (hipStream_t)stream, xb, dyb, dw2)
+                                : run_wgrad<float>(d, x, dy, dw, Cr, Kr, accumulate, ws, ws_bytes, (hipStream_t)stream, xb, dyb, dw2);
+}
+
 // Weight gradient of TWO applications of one layer (same shape) in one launch: dw (+)= wgrad(x0, dy0) + wgrad(x1, dy1).
 // Only the shapes of the all-taps 3x3 kernel (SGG_EUNSUPPORTED otherwise: call sgg_conv2d_bwd_weight twice);
 // workspace as for a single call.
@@ -4076,6 +4110,10 @@ int sgg_deconv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w,
 int sgg_deconv2d_bwd_weight(const sgg_conv_desc* d, const void* x, const void* dy, float* dw, int Cr, int Kr, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     // deconv input x plays the conv-output role, deconv output-gradient dy the conv-input role
     return sgg_conv2d_bwd_weight(d, dy, x, dw, Cr, Kr, accumulate, ws, ws_bytes, stream);
+}
+int sgg_deconv2d_bwd_weight_group2(const sgg_conv_desc* d, const void* x, const void* dy, float* dw, float* dw2, int Cr, int Kr, int accumulate,
+                                   void* ws, size_t ws_bytes, void* stream) {
+    return sgg_conv2d_bwd_weight_group2(d, dy, x, dw, dw2, Cr, Kr, accumulate, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -47,6 +47,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const char* dy, float* partial, int64_t P, int C) {
     constexpr int VEC = ET<T>::VEC;
     const int CV = C / VEC;
+    // grouped call (sgg_bias_grad_group2): blockIdx.y = 1 is the second network's tensor, right behind the first one's
+    dy += (size_t)blockIdx.y * P * C * sizeof(T);
+    partial += (size_t)blockIdx.y * gridDim.x * C;
     const int64_t p0 = (int64_t)blockIdx.x * BG_ROWS, p1 = p0 + BG_ROWS < P ? p0 + BG_ROWS : P;
     __shared__ float red[256][VEC + 1];
     for (int cvb = 0; cvb < CV; cvb += 256) {
@@ -77,8 +80,9 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const char* dy, flo
 // one 1024-thread block per 16 channels; 64 chunk-lanes per channel, four independent loads in flight each, combined in
 // fixed order (the head's bias gradient has 1 024 chunks of 8 channels: 4 lanes walking them one dependent load after
 // the other took 25 us)
-__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* partial, float* out, int C, int Cr, int chunks, int accumulate) {
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* partial, float* out, int C, int Cr, int chunks, int accumulate, float* out2) {
     __shared__ double red[64][16];
+    if (blockIdx.y) { partial += (size_t)chunks * C; out = out2; }
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + tx;
     double s = 0.0;
@@ -621,7 +625,20 @@ int sgg_bias_grad(const void* dy, float* db, int64_t P, int C, int C_real, int a
     if (dtype == SGG_BF16) hipLaunchKernelGGL(colsum_partial_kernel<bf16>, dim3(chunks), dim3(256), 0, s, (const char*)dy, (float*)ws, P, C);
     else if (dtype == SGG_F32) hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(chunks), dim3(256), 0, s, (const char*)dy, (float*)ws, P, C);
     else return SGG_EINVAL;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, (const float*)ws, db, C, C_real, chunks, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, (const float*)ws, db, C, C_real, chunks, accumulate, (float*)nullptr);
+    return sgg_check_launch();
+}
+// Grouped call: dy holds the two networks' tensors back to back (P pixels each); db / db2 are their bias gradients.  Same
+// arithmetic per network as sgg_bias_grad (bit-identical), two launches instead of four.  ws >= 2 x sgg_bias_grad_workspace(P, C).
+int sgg_bias_grad_group2(const void* dy, float* db, float* db2, int64_t P, int C, int C_real, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !db || !db2 || P <= 0 || C <= 0 || C % SGG_CPAD || C_real <= 0 || C_real > C) return SGG_EINVAL;
+    if (!ws || ws_bytes < 2 * sgg_bias_grad_workspace(P, C)) return SGG_EWORKSPACE;
+    int chunks = (int)((P + BG_ROWS - 1) / BG_ROWS);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SGG_BF16) hipLaunchKernelGGL(colsum_partial_kernel<bf16>, dim3(chunks, 2), dim3(256), 0, s, (const char*)dy, (float*)ws, P, C);
+    else if (dtype == SGG_F32) hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(chunks, 2), dim3(256), 0, s, (const char*)dy, (float*)ws, P, C);
+    else return SGG_EINVAL;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16, 2), dim3(1024), 0, s, (const float*)ws, db, C, C_real, chunks, accumulate, db2);
     return sgg_check_launch();
 }
 

@@ -354,6 +354,15 @@ def conv_dgrad_group2(g: ConvGeom, dy, w_dgrad, w_dgrad2, addend=None):
     return dx
 
 
+def conv_wgrad_group2(g: ConvGeom, x, dy, dw, dw2, accumulate=False):
+    """dw (+)= wgrad(x[:N], dy[:N]), dw2 (+)= wgrad(x[N:], dy[N:]): both networks' slabs, one reduce launch."""
+    assert tuple(x.shape) == _stacked(g.x_shape) and tuple(dy.shape) == _stacked(g.y_shape) and dw.shape == dw2.shape
+    ws = workspace(2 * g.ws_wgrad, x.device)
+    fn = A.lib().sgg_deconv2d_bwd_weight_group2 if g.is_deconv else A.lib().sgg_conv2d_bwd_weight_group2
+    A.check(fn(C.byref(g.desc), _p(x), _p(dy), _p(dw), _p(dw2), dw.shape[2], dw.shape[3], int(accumulate), _p(ws), ws.numel(), _s()),
+            "bwd_weight_group2")
+
+
 def deconv_fwd_group2(g: ConvGeom, x, w_dgrad, bias, w_dgrad2, bias2, act=A.ACT_NONE, leak=0.0):
     assert tuple(x.shape) == _stacked(g.x_shape) and g.is_deconv
     y = torch.empty(_stacked(g.y_shape), dtype=x.dtype, device=x.device)
@@ -403,6 +412,15 @@ def bias_grad(dy, db, accumulate=False):
     need = int(A.lib().sgg_bias_grad_workspace(P, Cp))
     ws = workspace(need, dy.device)
     A.check(A.lib().sgg_bias_grad(_p(dy), _p(db), P, Cp, db.numel(), int(accumulate), dt(dy), _p(ws), ws.numel(), _s()), "bias_grad")
+
+
+def bias_grad_group2(dy, db, db2, accumulate=False):
+    """Two networks' tensors stacked on the batch dimension: db (+)= colsum(dy[:N]), db2 (+)= colsum(dy[N:])."""
+    Cp = dy.shape[-1]
+    P = dy.numel() // Cp // 2
+    need = 2 * int(A.lib().sgg_bias_grad_workspace(P, Cp))
+    ws = workspace(need, dy.device)
+    A.check(A.lib().sgg_bias_grad_group2(_p(dy), _p(db), _p(db2), P, Cp, db.numel(), int(accumulate), dt(dy), _p(ws), ws.numel(), _s()), "bias_grad_group2")
 
 
 # ----------------------------------------------------------------------------- instance norm / activations

@@ -662,7 +662,9 @@ class _PairUnit:
             # (the conv bias in front of an instance norm has an identically zero gradient: left at 0)
         else:
             dxc = K.act_bwd(dy, xc, ua.act, ua.leak) if ua.act != A.ACT_NONE else dy
-            if param_grads:
+            if param_grads and ua.net.group2:
+                K.bias_grad_group2(dxc, PA.g(na + "_b"), PB.g(nb + "_b"), accumulate=True)
+            elif param_grads:
                 for u, sl in halves:
                     K.bias_grad(dxc[sl], u.net.P.g(u.name + "_b"), accumulate=True)
         if param_grads:
@@ -670,9 +672,13 @@ class _PairUnit:
             pa, pb = ua._pending, ub._pending
             quad = (ua.kind == "conv" and g.wgrad_pair and ua.net.pair_wgrads and ub.net.pair_wgrads and pa is not None and pb is not None
                     and pa[0].x_shape == g.x_shape and pb[0].x_shape == g.x_shape)
+            defer = ua.kind == "conv" and g.wgrad_pair and (ua.net.pair_wgrads or ub.net.pair_wgrads)   # the 3x3 layers' two-application form
             if quad and K.conv_wgrad_pair2(g, (pa[1], pa[2], x[halves[0][1]], dxc[halves[0][1]], PA.g(na + "_w")),
                                            (pb[1], pb[2], x[halves[1][1]], dxc[halves[1][1]], PB.g(nb + "_w")), accumulate=True):
                 ua._pending = ub._pending = None
+            elif ua.net.group2 and not defer and pa is None and pb is None:
+                # both networks' weight gradients as one grouped call: two main kernels, one slab reduce (bit-identical to two calls)
+                K.conv_wgrad_group2(g, x, dxc, PA.g(na + "_w"), PB.g(nb + "_w"), accumulate=True)
             else:
                 for u, sl in halves:
                     u.weight_grad(g, x[sl], dxc[sl])

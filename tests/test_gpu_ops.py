@@ -535,6 +535,23 @@ def test_group2_launches_equal_two_single_calls(sg, cfg):
         for k in range(2):
             ref = K.conv_dgrad(g, dy[k * N:(k + 1) * N], ws_[k][1], None if ad is None else ad[k * N:(k + 1) * N])
             assert torch.equal(dx2[k * N:(k + 1) * N], ref), ("dgrad", ad is not None, k)
+    for accumulate in (False, True):                     # bias gradient of both networks in one call
+        base = [r(Co), r(Co)]
+        dbs = [b.clone() for b in base]
+        K.bias_grad_group2(dy, dbs[0], dbs[1], accumulate=accumulate)
+        for k in range(2):
+            ref = base[k].clone()
+            K.bias_grad(dy[k * N:(k + 1) * N], ref, accumulate=accumulate)
+            assert torch.equal(dbs[k], ref), ("bias grad", accumulate, k)
+    # weight gradients: two main kernels + ONE slab reduce vs two full calls (also accumulating onto existing values)
+    for accumulate in (False, True):
+        base = [r(R, R, Ci, Co), r(R, R, Ci, Co)]
+        dws = [b.clone() for b in base]
+        K.conv_wgrad_group2(g, x, dy, dws[0], dws[1], accumulate=accumulate)
+        for k in range(2):
+            ref = base[k].clone()
+            K.conv_wgrad(g, x[k * N:(k + 1) * N], dy[k * N:(k + 1) * N], ref, accumulate=accumulate)
+            assert torch.equal(dws[k], ref), ("wgrad", accumulate, k)
     if stride == 2 and padding == "SAME" and H % 2 == 0 and W % 2 == 0:
         # the same weights as a Conv2DTranspose (module.py:254,258): x' = (2N, H/2, W/2, Co) -> (2N, H, W, Ci)
         gd = K.deconv_geom(N, H // 2, W // 2, Co, Ci, R, R, 2, dt)
@@ -546,3 +563,10 @@ def test_group2_launches_equal_two_single_calls(sg, cfg):
             sl = slice(k * N, (k + 1) * N)
             assert torch.equal(yt[sl], K.deconv_fwd(gd, xt[sl], ws_[k][1], bt[k], A.ACT_RELU, 0.0)), ("deconv fwd", k)
             assert torch.equal(dxt[sl], K.deconv_dgrad(gd, x[sl], ws_[k][0])), ("deconv dgrad", k)
+        dwt = [torch.empty((R, R, Ci, Co), device="cuda") for _ in range(2)]          # Keras transpose kernel: (kh, kw, out, in)
+        K.conv_wgrad_group2(gd, xt, x, dwt[0], dwt[1])
+        for k in range(2):
+            sl = slice(k * N, (k + 1) * N)
+            ref = torch.empty_like(dwt[k])
+            K.deconv_wgrad(gd, xt[sl], x[sl], ref)
+            assert torch.equal(dwt[k], ref), ("deconv wgrad", k)

@@ -89,12 +89,18 @@ def measured_traffic(kernel, gflop_per_launch=None):
     for name in TRAFFIC_FILES:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                e = json.load(f)[kernel]
+                table = json.load(f)
         except Exception:
             continue
+        # the entry collected on the launch size closest to this one ("..._pair": the 16-image launches of the paired cycle step)
+        cands = [k for k in (kernel, kernel + "_pair") if k in table]
+        if not cands:
+            continue
+        key = min(cands, key=lambda k: abs(table[k].get("gflop_per_launch", 77.309411328) - (gflop_per_launch or 77.309411328)))
+        e = table[key]
         b = e["hbm_bytes_per_launch"]                       # (helper kernels of the call are listed separately in the file)
         g = e.get("gflop_per_launch", 77.309411328)
-        note = f"FETCH_SIZE (doubled, gfx950) + WRITE_SIZE per launch of the main kernel, profiles/{name}"
+        note = f"FETCH_SIZE (doubled, gfx950) + WRITE_SIZE per launch of the main kernel, profiles/{name} [{key}]"
         if gflop_per_launch is not None and abs(g - gflop_per_launch) > 1e-3 * g:
             b = b * gflop_per_launch / g
             note += f" (collected on a {g:.1f} GFLOP launch, scaled to this launch's {gflop_per_launch:.1f})"

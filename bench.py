@@ -358,8 +358,11 @@ def main():
         model._stage_inputs(); model._record()
     barrier()
     t0 = time.perf_counter()
+    t_switch = None
     for i in range(a.steps):
-        if a.graph and i == a.steps - eager_tail:
+        if a.graph and eager_tail and i == a.steps - eager_tail:
+            torch.cuda.synchronize()               # (one queue drain inside the timed region: the replayed and the eagerly
+            t_switch = time.perf_counter()         #  dispatched steps are also reported separately)
             model.use_graph = False
         if timing and (not a.graph or i >= a.steps - eager_tail):
             prof.mode = "live"
@@ -394,6 +397,8 @@ def main():
                        "dispatch": (f"HIP-graph replay of the recorded step (sggan_amd/graph.py) for {a.steps - eager_tail} of the {a.steps} timed "
                                     f"steps, eager launches for the last {eager_tail} (the ones whose kernels are timed with events)"
                                     if a.graph else "eager launches from Python")},
+            "graph_steps_images_per_sec": (a.batch * world * (a.steps - eager_tail) / (t_switch - t0)) if t_switch else None,
+            "eager_tail_images_per_sec": (a.batch * world * eager_tail / (elapsed - (t_switch - t0))) if t_switch else None,
             "step_tflops": ips * gflop_img / 1e3,
             "step_frac_of_mfma_peak": ips * gflop_img / 1e3 / (PEAK_BF16_TFLOPS * world),
             "gen_loss": gl, "disc_loss": dl,

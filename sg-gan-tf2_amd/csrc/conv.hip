@@ -2370,6 +2370,16 @@ __global__ __launch_bounds__(512) void conv_halo_narrow_in_kernel(ConvArgs a, in
     }
     // origin of the source halo relative to the tile: fwd reads (y - p + r), the data-gradient (y + p - r)
     const int oy = flip ? a.pad_t - (a.R - 1) : -a.pad_t, ox = flip ? a.pad_l - (a.S - 1) : -a.pad_l;
+    // per 16-byte k-chunk q: byte offset of its tap inside the halo, ((tr * HWd + ts) * PXB + sub * 16); chunks past the last
+    // tap read tap 0 (their weights are zero)
+    int* sTap = reinterpret_cast<int*>(sH + (size_t)HP * PXB);
+    for (int q = tid; q < ksteps * 4; q += 512) {
+        int tap = q / CPV, sub = q - tap * CPV;
+        if (tap >= taps) { tap = 0; sub = 0; }
+        int tr = tap / a.S, ts = tap - tr * a.S;
+        if (flip) { tr = a.R - 1 - tr; ts = a.S - 1 - ts; }
+        sTap[q] = (tr * HWd + ts) * PXB + sub * 16;
+    }
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int b = tile;
@@ -2399,18 +2409,18 @@ __global__ __launch_bounds__(512) void conv_halo_narrow_in_kernel(ConvArgs a, in
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int ks = 0; ks < ksteps; ++ks) {
-            int qq = ks * 4 + fq;                        // this lane's 16-byte k-chunk
-            int tap = qq / CPV, sub = qq - tap * CPV;
-            if (tap >= taps) { tap = 0; sub = 0; }       // weights are zero there; keep the halo read in bounds
-            int tr = tap / a.S, ts = tap - tr * a.S;
-            if (flip) { tr = a.R - 1 - tr; ts = a.S - 1 - ts; }
+            const int qq = ks * 4 + fq;                  // this lane's 16-byte k-chunk
+            // halo byte offset of this lane's tap (tr, ts, sub): a table built once per block (the two integer divisions and the
+            // flip per k-step and lane made this loop VALU-issue bound: PMC showed the matrix pipes 34 % busy, 44 % of wave cycles
+            // issue-stalled)
+            const int toff = sTap[qq];
             u32x4 fw[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) fw[i] = ld16(sW + (i * 16 + frow) * wpitch + qq * 16);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int y = 2 * wave + (j >> 1), x = (j & 1) * 16 + frow;
-                u32x4 fp = ld16(sH + ((y + tr) * HWd + x + ts) * PXB + sub * 16);
+                u32x4 fp = ld16(sH + (y * HWd + x) * PXB + toff);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if constexpr (sizeof(T) == 2) {
@@ -2461,7 +2471,8 @@ template <typename T>
 static int launch_halo_narrow_in(const sgg_conv_desc* d, const ConvArgs& a, int flip, hipStream_t s) {
     const int cpv = 8 / (16 / (int)sizeof(T));
     const int ksteps = (d->R * d->S * cpv + 3) / 4;
-    size_t lds = (size_t)64 * (((ksteps * 4) | 1) * 16) + (size_t)(HALO_TH + d->R - 1) * (HALO_TW + d->S - 1) * 8 * sizeof(T);
+    size_t lds = (size_t)64 * (((ksteps * 4) | 1) * 16) + (size_t)(HALO_TH + d->R - 1) * (HALO_TW + d->S - 1) * 8 * sizeof(T)
+                 + (size_t)ksteps * 4 * sizeof(int);                       // + the tap-offset table
     auto kern = conv_halo_narrow_in_kernel<T>;
     SGG_LDS_ATTR(kern, 160 * 1024);
     int ntiles = d->N * (d->H / HALO_TH) * (d->W / HALO_TW);
@@ -3140,6 +3151,11 @@ static int launch_gemm(const ConvArgs& a, hipStream_t s) {
             // (a 4-stage ring of 64-byte K-slices was measured 3-5 % slower on the residual conv and is not built)
             if (DC >= 256 && Mmax * ((DC + 255) / 256) >= 256 * 160)
                 return launch_glds_cfg<T, MODE, 256, 256, 2, 8, 128, 2>(a, Mmax, DC, classes, s);
+            // short reductions (<= 16 K-tiles: the 64-channel stride-2 layers c2 forward / d2 data gradient / D.h1 forward): a
+            // 256x128 block is alone on its CU and spends a third of its life in prologue and epilogue; two 128x128 blocks per
+            // CU cover each other: 93.7 -> 84.4 us (c2), 25.3 -> 22.7 us (D.h1); the 4-wave 128x64 tile (three blocks): 115 us
+            if (DC >= 128 && (MODE == MODE_FWD ? a.R * a.S * a.C : a.R * a.S * a.K) <= 1024)
+                return launch_glds_cfg<T, MODE, 128, 128, 2, 8>(a, Mmax, DC, classes, s);
             if (DC >= 128 && Mmax * ((DC + 127) / 128) >= 256 * 160)
                 return launch_glds_cfg<T, MODE, 256, 128, 4, 8, 128, GLDS_NS_256x128>(a, Mmax, DC, classes, s);
             // 128x128 with 8 waves (2 per SIMD, two blocks per CU): the 4-wave variant ran at one wave per SIMD with

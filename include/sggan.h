@@ -141,6 +141,19 @@ int sgg_conv2d_fwd_stats_pair(const sgg_conv_desc* d, const void* x, const void*
                               const float* bias2, int nsplit, void* y, float* partial, void* ws, size_t ws_bytes, void* stream);
 int sgg_conv2d_bwd_data_pair(const sgg_conv_desc* d, const void* dy, const void* w_dgrad, const void* w_dgrad2, int nsplit,
                              const void* addend, void* dx, void* ws, size_t ws_bytes, void* stream);
+/* "Normalise on load" -- conv -> InstanceNormalization -> ReLU -> conv (the residual block, module.py:211-215) without the
+ * norm's apply pass over the tensor: x_raw is the FIRST conv's raw output, x_stats its (mean, rstd)[N][C]
+ * (sgg_instnorm_finalize over the first conv's statistics rows), x_gamma / x_beta the norm's parameters.  The second conv
+ * applies relu(x * gamma * rstd + beta - mean * gamma * rstd) to its operand tiles after they land in LDS and writes the
+ * normalised tensor to x_norm on the way (the backward pass needs it as this conv's weight-gradient operand).  y, partial:
+ * as sgg_conv2d_fwd_stats.  w2 == NULL: one network; else the lockstep pair (images >= nsplit use w2 / bias2 / x_gamma2 /
+ * x_beta2).  x_norm, y and partial are bit-identical to sgg_instnorm_fwd_partial(act = RELU) followed by sgg_conv2d_fwd_stats.
+ * Supported where sgg_conv2d_fwd_normload_supported(d) returns 1 (bf16, REFLECT 3x3 stride 1, C <= 512). */
+int sgg_conv2d_fwd_normload_supported(const sgg_conv_desc* d);
+int sgg_conv2d_fwd_stats_normload(const sgg_conv_desc* d, const void* x_raw, const float* x_stats, const float* x_gamma, const float* x_beta,
+                                  const float* x_gamma2, const float* x_beta2, void* x_norm, const void* w_fwd, const float* bias,
+                                  const void* w_fwd2, const float* bias2, int nsplit, void* y, float* partial,
+                                  void* ws, size_t ws_bytes, void* stream);
 /* bwd_weight: dw_hwio[R][S][C_real][K_real] f32, overwritten (accumulate=0) or added to (accumulate=1: a network
  * applied twice in one step, model.py:186-187).  ws: sgg_conv2d_bwd_weight_workspace() bytes. */
 size_t sgg_conv2d_bwd_weight_workspace(const sgg_conv_desc* d);
@@ -218,6 +231,8 @@ int sgg_instnorm_fwd(const void* x, const float* gamma, const float* beta, const
 int sgg_instnorm_fwd_partial(const void* x, const float* gamma, const float* beta, const void* residual, void* y,
                              float* stats, const float* partial, int chunks, int N, int64_t HW, int C, float eps,
                              int act, float leak, int dtype, void* stream);
+/* only the finalize step of the above: stats[N][C][2] = (mean, rstd) from the partial sums (no pass over the tensor) */
+int sgg_instnorm_finalize(const float* partial, int chunks, float* stats, int N, int64_t HW, int C, float eps, void* stream);
 /* dx = d/dx of the above given dy (w.r.t. the post-activation output); dgamma/dbeta[C_real] f32 overwritten or
  * (accumulate=1) added to.  gamma/beta/stats are indexed over the padded C. */
 int sgg_instnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats,

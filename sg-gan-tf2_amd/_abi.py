@@ -56,6 +56,8 @@ SIGNATURES = {
     "sgg_conv2d_bwd_data_mixed": (_i, [_dp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "sgg_conv2d_pair_supported": (_i, [_dp]),
     "sgg_conv2d_fwd_stats_pair": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "sgg_conv2d_fwd_normload_supported": (_i, [_dp]),
+    "sgg_conv2d_fwd_stats_normload": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "sgg_conv2d_bwd_data_pair": (_i, [_dp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "sgg_conv2d_fwd_group2": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _sz, _vp]),
     "sgg_conv2d_bwd_data_group2": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -80,6 +82,7 @@ SIGNATURES = {
     "sgg_instnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _i, _f, _i, _vp, _sz, _vp]),
     "sgg_instnorm_fwd_partial": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _f, _i, _f, _i, _vp]),
     "sgg_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
+    "sgg_instnorm_finalize": (_i, [_vp, _i, _vp, _i, _i64, _i, _f, _vp]),
     "sgg_instnorm_fwd_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _f, _i, _f, _i, _vp, _sz, _vp]),
     "sgg_instnorm_fwd_partial_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _f, _i, _f, _i, _vp]),
     "sgg_instnorm_bwd_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),

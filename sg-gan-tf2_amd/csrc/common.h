@@ -127,6 +127,20 @@ __device__ inline void dma16_to_lds(const void* gsrc, __attribute__((address_spa
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m) : "memory", "m0");
 }
 
+// the same with the address as a UNIFORM 64-bit base (an SGPR pair) + a 32-bit per-lane byte offset: no 64-bit VGPR address
+// per instruction (the bases of the pieces of one tile differ by scalars -- SALU adds instead of per-lane 64-bit VALU adds,
+// and nothing for hipcc to hoist into registers across the main loop)
+__device__ inline void dma16_to_lds_s(const void* sbase, uint32_t voff, __attribute__((address_space(3))) void* lds_wave_base) {
+    const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave_base);
+    // (readfirstlane: a no-op for a value hipcc already holds in SGPRs; where its divergence analysis is unsure the "s"
+    // constraint alone is handed a VGPR pair, which does not assemble)
+    const uint64_t b = (uint64_t)(uintptr_t)sbase;
+    // (the builtin returns a SIGNED int: without the uint32_t casts a low half >= 0x80000000 sign-extends over the high half)
+    const uint64_t sb = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b) |
+                        ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(m) : "memory", "m0");
+}
+
 __device__ inline void dma4_to_lds(const void* gsrc, __attribute__((address_space(3))) void* lds_wave_base) {   // 4 bytes per lane at m0 + 4 * lane
     const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave_base);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(m) : "memory", "m0");

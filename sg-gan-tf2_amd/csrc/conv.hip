@@ -47,6 +47,13 @@ struct ConvArgs {
     const float* ngamma; //   gamma, beta [DC]
     const float* nbeta;
     int nact; float nleak;   // and the activation fused behind it
+    // Forward, "normalise on load" (NORM variant of the halo 3x3 kernel): src is the RAW output of the conv before the instance
+    // norm in front of this conv; the kernel applies relu(x * A + B) (A = gamma * rstd, B = beta - mean * A, from nstats /
+    // ngamma / nbeta; second network of a pair: ngamma2 / nbeta2) to the landed halo rows in LDS and writes the normalised
+    // tensor -- which the backward pass needs as this conv's weight-gradient operand -- to nout on the way.
+    char* nout;
+    const float* ngamma2;
+    const float* nbeta2;
     float* partial;      // split-K (v2): f32 slabs [ksplit][pdst][DC]
     int ksplit;          // 1 = no split
     const char* wmat2;   // halo 3x3 kernels, two networks on one stacked batch: images >= nsplit use wmat2 / bias2
@@ -741,6 +748,15 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a_in) 
 #ifndef H3_GJ
 #define H3_GJ 4                                        // pixel fragments per MFMA group of the main loop (x 4 weight fragments = 16 MFMAs)
 #endif
+#ifndef H3_NORM_AT
+#define H3_NORM_AT 1                                   // NORM: after which MFMA group of the step (0..3) the row transform runs
+#endif
+#ifndef H3_VADDR
+#define H3_VADDR 0                                     // 1: every DMA with a 64-bit per-lane address (the round-2 form; A/B switch)
+#endif
+#ifndef H3_NORM_ABL
+#define H3_NORM_ABL 0                                  // timing experiments only (wrong results): 1 no store of the normalised rows, 2 no in-loop transform, 4 no prologue transform
+#endif
 #define H3_PITCH 136                                   // halo row pitch in pixels (130 used; multiple of 8 = one DMA)
 #define H3_HALO_BYTES (4 * H3_PITCH * 128)
 #define H3_PATCH_ROWS 40                               // 2 tile rows x 2 sides x 9 taps = 36, rounded to whole DMAs
@@ -757,8 +773,18 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a_in) 
 //            pixels) through a per-lane address select in the first / last pixel fragment.
 // PAIR: two networks of one shape on a stacked batch, images >= a.nsplit take the second weight set (a compile-time flag so
 // that the launches of the paired cycle step show under their own name in a kernel trace: they cover twice the images)
-template <int MODE, bool FOLD, int STATS = 0, bool PAIR = false>   // STATS: 0 none, 1 forward norm sums, 2 backward norm sums
+// NORM (forward only): the source is the RAW output of the previous conv and the instance norm + ReLU between the two convs
+// (module.py:212-214) is applied to the halo rows after they land in LDS -- by the four waves that issue no DMAs, after their
+// MFMAs of the step after the row's DMA, one step before its first use -- so the separate apply pass over the tensor (a read
+// and a write of every activation) disappears; the normalised interior rows are written to a.nout from the same registers (the
+// weight gradient of this conv reads them in the backward pass), a store stream that runs under the MFMAs.  Same arithmetic
+// as in_apply_kernel (x * A + B, max 0, RNE to bf16): the results are bit-identical to the two separate calls.
+// SRC: how the source tensor is padded -- 0 zeros (every data gradient; the zero-padded forward), 1 REFLECT (forward),
+// 2 REFLECT + normalise on load.  A template parameter because the two paddings address their halo DMAs differently (below).
+template <int MODE, bool FOLD, int STATS = 0, bool PAIR = false, int SRC = 0>   // STATS: 0 none, 1 forward norm sums, 2 backward norm sums
 __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
+    constexpr bool NORM = SRC == 2;
+    static_assert(SRC == 0 || (MODE == MODE_FWD && !FOLD), "REFLECT sources / normalise-on-load exist for the forward conv only");
     constexpr int BN = 256, WGM = 2, WGN = 4, WM = 128, WN = 64, MI = 8, NI = 4, BKB = 128, KK = 2;
     constexpr int QA = 4;                              // weight rows per thread per tile (8 waves x 8 rows x 4)
     constexpr int RPP = 64;
@@ -801,7 +827,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
 
     // ---- halo DMA: one wave-instruction = 8 halo pixels x 128 B; a halo row is 17 of them (wave, wave+8, wave+16)
     const int hpos = lane & 7, hsub = lane >> 3;
-    const bool mirror = MODE == MODE_FWD && a.reflect;                     // the data gradient always zero-pads dy
+    constexpr bool mirror = SRC != 0;                                      // (the data gradient always zero-pads dy)
+    // DMA addressing: a 64-bit per-lane address per piece (zero-padded sources select against the zero page).  The other form
+    // -- a uniform base in an SGPR pair + a 32-bit lane offset, possible for REFLECT sources, where every halo pixel is an image
+    // pixel, and for the weight tiles -- frees ~16 VGPRs but costs SALU work and a scalar branch per piece on the issuer waves:
+    // in the step the paired forward ran at 0.484 of peak with it against 0.495 without, and the paired data gradient (weight
+    // tiles only) at 0.415 against 0.451 (profiles/r03_ab_dma_addressing.txt).  Only the normalise-on-load variant uses it: it
+    // needs the registers.  (What did pay is the padding mode as a template parameter: 0.472 -> 0.495.)
+    constexpr bool SADDR = SRC == 2 && !H3_VADDR;
     const char* vrows = FOLD ? a.fold + (size_t)a.N * a.H * 18 * SC * 2 : nullptr;   // [N][2][W][SC] after the patches
     // (Walking the channel chunks in a per-block rotated order -- so that the blocks of one XCD do not all want the
     // same weight tile at the same moment -- measured 1-2 % slower: first-touch L2 misses are not what the tiles wait for.)
@@ -835,8 +868,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             // address: position hpos of row r holds chunk (hpos - (r & 6)) & 7.
             const int hrow_ = k * H3_PITCH + hp;
             const int schunk = H3_ROT ? ((hpos - (hrow_ & 6)) & 7) : (hpos ^ ((hrow_ >> 1) & 7));
-            const char* src = ok ? rowp + (size_t)wi * SC * 2 + (schunk << 4) : zero;
-            dma16_to_lds(src, (__attribute__((address_space(3))) void*)(lH + (k * H3_PITCH + q * 8) * 128));
+            if (SADDR) {
+                // every halo pixel is an image pixel (the six filler columns of the pitch read mirrored pixels nobody uses):
+                // uniform row base + a 32-bit lane offset
+                dma16_to_lds_s(rowp, (uint32_t)(wi * SC * 2 + (schunk << 4)), (__attribute__((address_space(3))) void*)(lH + (k * H3_PITCH + q * 8) * 128));
+            } else {
+                const char* src = ok ? rowp + (size_t)wi * SC * 2 + (schunk << 4) : zero;
+                dma16_to_lds(src, (__attribute__((address_space(3))) void*)(lH + (k * H3_PITCH + q * 8) * 128));
+            }
         }
     };
 
@@ -861,20 +900,79 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
 
     // ---- weight-tile DMA: 32 wave-instructions of 8 rows x 128 B per tile; instruction d covers rows 8d .. 8d+7, lane l row
     // 8d + l/8 at chunk position l%8 (swizzled by the row: key = (l/16 + 4(d&1)) & 7, i.e. the d-even key with bit 2 flipped)
+    // Addressing: a uniform base per instruction (tile column, 8-row group, tap, chunk: SGPR arithmetic) + ONE per-lane offset
+    // for the whole kernel (row within the group and the swizzled chunk; d & 1 == vw & 1 because nw is even).  DC is a
+    // multiple of 8, so an 8-row group is inside the matrix or outside it as a whole: a scalar test.
     const int wl = lane >> 3;
-    const char* wbase = wmat_n + (size_t)(n0 + wl) * wrow * 2;
     const int wsw = ((lane & 7) ^ ((lane >> 4) & 7)) << 4;
-    const size_t wstride8 = (size_t)8 * wrow * 2;
+    const uint32_t wvoff0 = (uint32_t)(wl * wrow * 2 + wsw), wvoff1 = (uint32_t)(wl * wrow * 2 + (wsw ^ 64));
     auto load_w = [&](int stg, int chunk, int tap, int vw, int nw) {
-        const int off = (tap * SC + chunk * 64) * 2;
+        const char* const tbase = wmat_n + ((size_t)n0 * wrow + tap * SC + chunk * 64) * 2;
+        const uint32_t wvoff = (vw & 1) ? wvoff1 : wvoff0;
         lds_char* sQ = lB + stg * (256 * 128);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int d = vw + nw * j;
             if (d >= 32) break;
-            const bool ok = n0 + d * 8 + wl < DC;
-            const char* src = ok ? wbase + d * wstride8 + off + (wsw ^ ((d & 1) << 6)) : zero;
-            dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sQ + d * 8 * 128));
+            if (!SADDR) {
+                const bool ok = n0 + d * 8 + wl < DC;
+                const char* src = ok ? wmat_n + (size_t)(n0 + wl) * wrow * 2 + d * ((size_t)8 * wrow * 2) + (tap * SC + chunk * 64) * 2 + (wsw ^ ((d & 1) << 6)) : zero;
+                dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sQ + d * 8 * 128));
+            } else if (n0 + d * 8 < DC) dma16_to_lds_s(tbase + (size_t)d * 8 * wrow * 2, wvoff, (__attribute__((address_space(3))) void*)(sQ + d * 8 * 128));
+            else dma16_to_lds(zero, (__attribute__((address_space(3))) void*)(sQ + d * 8 * 128));
+        }
+    };
+
+    // ---- NORM: halo row k (just landed, chunk `chunk` of the source channels) -> relu(x * A + B) in place.  A lane owns ONE
+    // 16-byte channel group (8 channels: its A / B stay in registers for the row) and walks the row's pixels, 8 per wave pass;
+    // rows 1 and 2 are this tile's own image rows: their 128 interior pixels also go to a.nout (whole 128-byte lines).
+    float* const sNA = reinterpret_cast<float*>(smem + (FOLD ? H3_LDS_FOLD : H3_LDS));   // A[SC], then B[SC]
+    auto norm_row = [&](int k_, int chunk, int vw, int nw) {
+        if constexpr (NORM) {
+            // (k through an opaque asm: the row's LDS / global addresses are loop invariants otherwise, and hipcc keeps all of
+            // them -- four rows x five pieces -- live across the main loop, next to 128 accumulators: scratch spills)
+            int k = k_;
+            asm volatile("" : "+s"(k));
+            const int c8 = lane & 7;
+            float A[8], B[8];
+            {
+                const float* pa = sNA + chunk * 64 + c8 * 8;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(pa), a1 = *reinterpret_cast<const f32x4*>(pa + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(pa + SC), b1 = *reinterpret_cast<const f32x4*>(pa + SC + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { A[e] = a0[e]; A[4 + e] = a1[e]; B[e] = b0[e]; B[4 + e] = b1[e]; }
+            }
+            const bool own_row = k == 1 || k == 2;
+            char* const orow = a.nout + ((((size_t)img * a.H + h0 + k - 1) * a.W + w0) * SC + chunk * 64 + c8 * 8) * 2;
+            auto piece_ptr = [&](int q) -> char* {
+                const int hrow_ = k * H3_PITCH + q * 8 + hsub;
+                const int pos = H3_ROT ? ((c8 + (hrow_ & 6)) & 7) : (c8 ^ ((hrow_ >> 1) & 7));
+                return sH + hrow_ * 128 + (pos << 4);
+            };
+            // up to five pieces per lane and row (17 pixel groups over 4 waves), in batches of <= 3 with the batch's reads issued
+            // together: one LDS latency per batch, and no more than 12 staging registers (the accumulators leave little room)
+#pragma unroll
+            for (int b0 = 0; b0 < 5; b0 += 3) {
+                u32x4 v[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int q = vw + nw * (b0 + u);
+                    if (b0 + u < 5 && q < 17) v[u] = ld16(piece_ptr(q));
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int q = vw + nw * (b0 + u);
+                    if (b0 + u >= 5 || q >= 17) continue;
+                    const int hp = q * 8 + hsub;
+                    float xv[8], o[8];
+                    ET<bf16>::unpack(v[u], xv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float t = xv[e] * A[e] + B[e]; o[e] = t > 0.f ? t : 0.f; }
+                    const u32x4 pk = ET<bf16>::pack(o);
+                    st16(piece_ptr(q), pk);
+                    if (!(H3_NORM_ABL & 1) && own_row && hp >= 1 && hp <= H3_TW) st16(orow + (size_t)(hp - 1) * SC * 2, pk);
+                }
+            }
         }
     };
 
@@ -887,6 +985,16 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     const int frow = lane & 15, fq = lane >> 4;
     const int fswQ = ((wn * WN + frow) >> 1) & 7;
 
+    if constexpr (NORM) {                                  // the norm's affine form per source channel of this image
+        const float* const gm = PAIR && img >= a.nsplit ? a.ngamma2 : a.ngamma;
+        const float* const bt = PAIR && img >= a.nsplit ? a.nbeta2 : a.nbeta;
+        for (int c = tid; c < SC; c += 512) {
+            const float mu = a.nstats[((size_t)img * SC + c) * 2], rs = a.nstats[((size_t)img * SC + c) * 2 + 1];
+            const float A = gm[c] * rs;
+            sNA[c] = A;
+            sNA[SC + c] = bt[c] - mu * A;
+        }
+    }
     // prologue: whole halo of chunk 0 + weight tile 0
 #pragma unroll
     for (int k = 0; k < 4; ++k) load_halo_row(k, 0, wave, 8);
@@ -894,6 +1002,15 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     load_w(0, 0, MODE == MODE_FWD ? 0 : 8, wave, 8);
     SGG_WAIT_VM0();
     __builtin_amdgcn_s_barrier();
+    if constexpr (NORM && !(H3_NORM_ABL & 4)) {
+        // the tile's own rows (1, 2: stored to a.nout) by the waves that issue no DMAs in the main loop, the neighbours' rows by
+        // the DMA issuers: those wait for vmcnt(0) at the end of every step and would sit out the stores' round trip to memory
+        // there (with the rows dealt to all eight waves the prologue cost 4.7 us per tile)
+        if ((wave >> 2) != H3_HALO_HALF) { norm_row(1, 0, wave & 3, 4); norm_row(2, 0, wave & 3, 4); }
+        else { norm_row(0, 0, wave & 3, 4); norm_row(3, 0, wave & 3, 4); }
+        SGG_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+    }
 
     const int ntiles = abl >= 5 ? 0 : nchunk * 9;
     int chunk = 0, tap = 0;                           // of the tile being multiplied
@@ -982,10 +1099,27 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
                     for (int i = 0; i < NI; ++i)
                         acc[i][jb + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8, fw[kk][i]), __builtin_bit_cast(bf16x8, fp[g & 1][jj]), acc[i][jb + jj], 0, 0, 0);
+                if constexpr (NORM) {
+                    // Rows land one step after their DMA was issued (the barrier below) and are first read two or more steps later
+                    // (see the refill schedule above): the step in between is where they are normalised, by the waves without
+                    // DMAs.  WHERE in the step: those waves have the matrix pipe to themselves while their SIMD partners issue the
+                    // DMAs (about half of the step's 64 MFMAs), then share it.  The ~1 300 cycles of VALU / LDS work of a row go
+                    // in the MIDDLE -- the partner wave, on the critical path, takes the whole pipe meanwhile; after the last
+                    // MFMA the same work measured fully exposed (paired launch +20 us).
+                    if (!(H3_NORM_ABL & 2) && g == H3_NORM_AT && (wave >> 2) != H3_HALO_HALF) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int vw = wave & 3;
+                        if (tap == 1 && chunk > 0) norm_row(2, chunk, vw, 4);
+                        if (tap == 4 && chunk > 0) norm_row(3, chunk, vw, 4);
+                        if (tap == 5 && chunk + 1 < nchunk) norm_row(0, chunk + 1, vw, 4);
+                        if (tap == 7 && chunk + 1 < nchunk) norm_row(1, chunk + 1, vw, 4);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
         }
         H3_STAMP(2);
-        SGG_WAIT_VM0();
+        if (!NORM || (wave >> 2) == H3_HALO_HALF || (wave >> 2) == H3_ISSUER_HALF) SGG_WAIT_VM0();   // (NORM: the other waves only have stores in flight)
         H3_STAMP(3);
         SGG_WAIT_LGKM0();
         H3_STAMP(4);
@@ -1452,10 +1586,11 @@ static bool halo3_ok(const ConvArgs& a, int mode, bool is_bf16) {
     return mode == MODE_FWD || mode == MODE_DGRAD;
 }
 
-template <int MODE, bool FOLD, int STATS = 0, bool PAIR = false>
+#define H3_NORM_MAXC 512                               // NORM: the A / B table behind the tiles holds this many source channels
+template <int MODE, bool FOLD, int STATS = 0, bool PAIR = false, int SRC = 0>
 static int launch_halo3(const ConvArgs& a, hipStream_t s) {
-    auto kern = conv3x3_halo_gemm_kernel<MODE, FOLD, STATS, PAIR>;
-    constexpr int lds = FOLD ? H3_LDS_FOLD : H3_LDS;
+    auto kern = conv3x3_halo_gemm_kernel<MODE, FOLD, STATS, PAIR, SRC>;
+    constexpr int lds = (FOLD ? H3_LDS_FOLD : H3_LDS) + (SRC == 2 ? H3_NORM_MAXC * 8 : 0);
     SGG_LDS_ATTR(kern, lds);
     const int DC = MODE == MODE_FWD ? a.K : a.C;
     const int64_t blocks = (int64_t)a.N * (a.H / 2) * (a.W / H3_TW) * ((DC + 255) / 256);
@@ -3016,7 +3151,7 @@ static bool desc_ok(const sgg_conv_desc* d) {
 
 static ConvArgs make_args(const sgg_conv_desc* d, const void* src, const void* w, const float* bias, void* dst, int act, float leak) {
     ConvArgs a;
-    a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst; a.addend = nullptr; a.fold = nullptr; a.stats = nullptr; a.nx = nullptr; a.nstats = nullptr; a.ngamma = nullptr; a.nbeta = nullptr; a.nact = 0; a.nleak = 0.f; a.partial = nullptr; a.ksplit = 1; a.pdst = 0; a.dst_f32 = 0; a.addend_f32 = 0; a.wmat2 = nullptr; a.bias2 = nullptr; a.nsplit = 0x7fffffff;
+    a.src = (const char*)src; a.wmat = (const char*)w; a.bias = bias; a.dst = (char*)dst; a.addend = nullptr; a.fold = nullptr; a.stats = nullptr; a.nx = nullptr; a.nstats = nullptr; a.ngamma = nullptr; a.nbeta = nullptr; a.nact = 0; a.nleak = 0.f; a.nout = nullptr; a.ngamma2 = nullptr; a.nbeta2 = nullptr; a.partial = nullptr; a.ksplit = 1; a.pdst = 0; a.dst_f32 = 0; a.addend_f32 = 0; a.wmat2 = nullptr; a.bias2 = nullptr; a.nsplit = 0x7fffffff;
     a.grp = 1; a.net_src = a.net_dst = a.net_add = a.net_part = 0;
     a.ablate = sgg_config().ablate;
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S; a.stride = d->stride;
@@ -3139,6 +3274,14 @@ static int launch_gemm(const ConvArgs& a, hipStream_t s) {
                 if (pair) return launch_halo3<MODE_DGRAD, false, 0, true>(a, s);
             }
             if constexpr (MODE == MODE_FWD) {
+                if (a.nout) {
+                    if (!a.stats || !a.reflect || a.C > H3_NORM_MAXC) return SGG_EUNSUPPORTED;
+                    return a.wmat2 ? launch_halo3<MODE_FWD, false, 1, true, 2>(a, s) : launch_halo3<MODE_FWD, false, 1, false, 2>(a, s);
+                }
+                if (a.reflect) {
+                    if (a.wmat2) return a.stats ? launch_halo3<MODE_FWD, false, 1, true, 1>(a, s) : launch_halo3<MODE_FWD, false, 0, true, 1>(a, s);
+                    return a.stats ? launch_halo3<MODE_FWD, false, 1, false, 1>(a, s) : launch_halo3<MODE_FWD, false, 0, false, 1>(a, s);
+                }
                 if (a.wmat2) return a.stats ? launch_halo3<MODE_FWD, false, 1, true>(a, s) : launch_halo3<MODE_FWD, false, 0, true>(a, s);
                 if (a.stats) return launch_halo3<MODE_FWD, false, 1>(a, s);
             }
@@ -3977,6 +4120,26 @@ int sgg_conv2d_fwd_stats_pair(const sgg_conv_desc* d, const void* x, const void*
     if (!x || !w || !w2 || !y || !partial || nsplit <= 0 || nsplit >= d->N) return SGG_EINVAL;
     ConvArgs a = make_args(d, x, w, bias, y, SGG_ACT_NONE, 0.f);
     a.stats = partial; a.wmat2 = (const char*)w2; a.bias2 = bias2; a.nsplit = nsplit;
+    return run_gemm<bf16, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream);
+}
+// "Normalise on load": conv(relu(instnorm(x_raw))) without the norm's apply pass -- x_raw is the previous conv's raw output,
+// x_stats its (mean, rstd) (sgg_instnorm_finalize), and the normalised tensor comes out in x_norm as a by-product.
+int sgg_conv2d_fwd_normload_supported(const sgg_conv_desc* d) {
+    if (!desc_ok(d) || d->dtype != SGG_BF16 || d->pad_mode != SGG_PAD_REFLECT || d->C > H3_NORM_MAXC) return 0;
+    return sgg_conv2d_fwd_stats_chunks(d) != 0;
+}
+int sgg_conv2d_fwd_stats_normload(const sgg_conv_desc* d, const void* x_raw, const float* x_stats, const float* x_gamma, const float* x_beta,
+                                  const float* x_gamma2, const float* x_beta2, void* x_norm, const void* w, const float* bias,
+                                  const void* w2, const float* bias2, int nsplit, void* y, float* partial,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    if (!sgg_conv2d_fwd_normload_supported(d)) return SGG_EUNSUPPORTED;
+    if (!x_raw || !x_stats || !x_gamma || !x_beta || !x_norm || !w || !y || !partial) return SGG_EINVAL;
+    ConvArgs a = make_args(d, x_raw, w, bias, y, SGG_ACT_NONE, 0.f);
+    a.stats = partial; a.nstats = x_stats; a.ngamma = x_gamma; a.nbeta = x_beta; a.nout = (char*)x_norm;
+    if (w2) {
+        if (!sgg_conv2d_pair_supported(d) || !x_gamma2 || !x_beta2 || nsplit <= 0 || nsplit >= d->N) return SGG_EINVAL;
+        a.wmat2 = (const char*)w2; a.bias2 = bias2; a.nsplit = nsplit; a.ngamma2 = x_gamma2; a.nbeta2 = x_beta2;
+    }
     return run_gemm<bf16, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream);
 }
 int sgg_conv2d_bwd_data_pair(const sgg_conv_desc* d, const void* dy, const void* w, const void* w2, int nsplit, const void* addend, void* dx,

@@ -583,6 +583,13 @@ int sgg_instnorm_bwd_partial(const void* dy, const void* x, const float* gamma, 
                              int accumulate, int act, float leak, int dtype, void* ws, size_t ws_bytes, void* stream) {
     return instnorm_bwd_partial_impl(dy, x, gamma, beta, stats, dx, dgamma, dbeta, partial, chunks, N, HW, C, C_real, accumulate, act, leak, dtype, ws, ws_bytes, stream, in_nosplit());
 }
+// (mean, rstd)[N][C] from per-chunk (sum, sumsq) rows -- the finalize step of sgg_instnorm_fwd_partial on its own, for a
+// consumer that applies the norm itself (sgg_conv2d_fwd_stats_normload)
+int sgg_instnorm_finalize(const float* partial, int chunks, float* stats, int N, int64_t HW, int C, float eps, void* stream) {
+    if (!partial || !stats || chunks <= 0 || N <= 0 || HW <= 0 || C <= 0 || C % SGG_CPAD) return SGG_EINVAL;
+    hipLaunchKernelGGL(in_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH, N), dim3(1024), 0, (hipStream_t)stream, partial, stats, HW, C, chunks, eps);
+    return sgg_check_launch();
+}
 static inline int in_pair_ok(const float* g2, const float* b2, int nsplit, int N) { return g2 && b2 && nsplit > 0 && nsplit < N; }
 int sgg_instnorm_fwd_pair(const void* x, const float* gamma, const float* beta, const float* gamma2, const float* beta2, int nsplit,
                           const void* residual, void* y, float* stats, int N, int64_t HW, int C, float eps, int act, float leak,

@@ -92,7 +92,7 @@ def same_pads(n_in: int, k: int, s: int):
 
 class ConvGeom:
     """Geometry of one Conv2D / Conv2DTranspose call site, resolved to an sgg_conv_desc."""
-    __slots__ = ("desc", "x_shape", "y_shape", "ws_wgrad", "ws_dgrad", "ws_fwd", "dtype", "is_deconv", "stats_chunks", "wgrad_pair", "bwd_stats_chunks", "dgrad_mixed", "pair_ok")
+    __slots__ = ("desc", "x_shape", "y_shape", "ws_wgrad", "ws_dgrad", "ws_fwd", "dtype", "is_deconv", "stats_chunks", "wgrad_pair", "bwd_stats_chunks", "dgrad_mixed", "pair_ok", "normload_ok")
 
     def __init__(self, desc, x_shape, y_shape, dtype, is_deconv):
         self.desc, self.x_shape, self.y_shape, self.dtype, self.is_deconv = desc, x_shape, y_shape, dtype, is_deconv
@@ -108,6 +108,7 @@ class ConvGeom:
         self.dgrad_mixed = (not is_deconv) and bool(L.sgg_conv2d_bwd_data_mixed_supported(C.byref(desc)))
         # a stacked batch of two networks can run forward (+stats) / data gradient as ONE launch with per-image weights
         self.pair_ok = (not is_deconv) and bool(L.sgg_conv2d_pair_supported(C.byref(desc)))
+        self.normload_ok = (not is_deconv) and bool(L.sgg_conv2d_fwd_normload_supported(C.byref(desc)))
         # workspaces of the two GEMM directions; a deconv runs the conv's data-gradient kernel forwards
         self.ws_fwd = int((L.sgg_deconv2d_fwd_workspace if is_deconv else L.sgg_conv2d_fwd_workspace)(C.byref(desc)))
         self.ws_dgrad = int((L.sgg_deconv2d_bwd_data_workspace if is_deconv else L.sgg_conv2d_bwd_data_workspace)(C.byref(desc)))
@@ -227,6 +228,34 @@ def conv_fwd_stats_pair(g: ConvGeom, x, w_fwd, bias, w_fwd2, bias2, nsplit):
                                               _p(ws), g.ws_fwd, _s()), "conv2d_fwd_stats_pair")
     if pr: pr.stop()
     return y, partial
+
+
+def conv_fwd_stats_normload(g: ConvGeom, x_raw, x_stats, gamma, beta, w_fwd, bias, pair=None):
+    """conv(relu(instnorm(x_raw))) with the norm applied to the operand tiles inside the conv kernel ("normalise on load",
+    sgg_conv2d_fwd_stats_normload).  x_stats: (mean, rstd) of x_raw (instnorm_finalize).  pair = (gamma2, beta2, w_fwd2,
+    bias2, nsplit) for the lockstep pair.  Returns (x_norm, y, partial): the normalised operand (a by-product the backward
+    pass needs), the conv output and its statistics rows -- all bit-identical to instnorm_fwd_partial + conv_fwd_stats."""
+    assert tuple(x_raw.shape) == g.x_shape and g.normload_ok and g.stats_chunks > 0
+    x_norm = torch.empty_like(x_raw)
+    y = torch.empty(g.y_shape, dtype=x_raw.dtype, device=x_raw.device)
+    partial = torch.empty((g.y_shape[0], g.stats_chunks, g.y_shape[3], 2), dtype=torch.float32, device=x_raw.device)
+    gamma2, beta2, w2, bias2, nsplit = pair if pair is not None else (None, None, None, None, 0)
+    pr = _prof("conv2d_fwd_normload" + ("_pair" if pair is not None else ""), g)
+    if pr: pr.start()
+    ws = workspace(g.ws_fwd, x_raw.device) if g.ws_fwd else None
+    A.check(A.lib().sgg_conv2d_fwd_stats_normload(C.byref(g.desc), _p(x_raw), _p(x_stats), _p(gamma), _p(beta), _p(gamma2), _p(beta2),
+                                                  _p(x_norm), _p(w_fwd), _p(bias), _p(w2), _p(bias2), nsplit, _p(y), _p(partial),
+                                                  _p(ws), g.ws_fwd, _s()), "conv2d_fwd_stats_normload")
+    if pr: pr.stop()
+    return x_norm, y, partial
+
+
+def instnorm_finalize(partial, HW, eps=1e-3):
+    """(mean, rstd)[N][C] from a conv's statistics rows partial[N][chunks][C][2] (no pass over the tensor)."""
+    N, chunks, Cp, _ = partial.shape
+    stats = torch.empty((N, Cp, 2), dtype=torch.float32, device=partial.device)
+    A.check(A.lib().sgg_instnorm_finalize(_p(partial), chunks, _p(stats), N, HW, Cp, eps, _s()), "instnorm_finalize")
+    return stats
 
 
 def conv_dgrad_pair(g: ConvGeom, dy, w_dgrad, w_dgrad2, nsplit, addend=None):

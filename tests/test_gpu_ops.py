@@ -570,3 +570,82 @@ def test_group2_launches_equal_two_single_calls(sg, cfg):
             ref = torch.empty_like(dwt[k])
             K.deconv_wgrad(gd, xt[sl], x[sl], ref)
             assert torch.equal(dwt[k], ref), ("deconv wgrad", k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    ("bench: residual-block shape, 8 images", 8, 64, 128, 256, 256),
+    ("small map, 4 row tiles", 3, 8, 128, 64, 64),
+    ("wide map, 128 source channels", 2, 16, 256, 128, 64),
+    ("512 source channels", 2, 6, 128, 512, 256),
+], ids=lambda c: c[0].split(":")[0])
+def test_normalise_on_load_conv_equals_norm_then_conv(sg, cfg):
+    """sgg_conv2d_fwd_stats_normload -- the residual block's conv -> InstanceNormalization -> ReLU -> conv (module.py:211-215)
+    with the norm applied to the operand tiles inside the second conv -- must be BIT-IDENTICAL to the norm's apply pass
+    followed by the plain conv: the normalised tensor it writes on the way, the conv output and the statistics rows; one
+    network and the lockstep pair."""
+    from sggan_amd import kernels as K
+    from sggan_amd import _abi as A
+    _, N, H, W, Ci, Co = cfg
+    dt = torch.bfloat16
+    g = K.conv_geom(N, H, W, Ci, Co, 3, 3, 1, "VALID", 1, dt)              # REFLECT pad 1
+    assert g.normload_ok and g.stats_chunks > 0
+    gen = torch.Generator().manual_seed(11)
+    r = lambda *sh: torch.randn(sh, generator=gen).cuda()
+    x_raw = (r(N, H, W, Ci) * 1.7 + 0.3).to(dt)
+    # statistics rows of x_raw in the producing conv's format: any chunking works for the finalize step
+    xf = x_raw.float().reshape(N, 4, H * W // 4, Ci)
+    part = torch.stack([xf.sum(2), (xf * xf).sum(2)], dim=-1).contiguous()
+    gam, bet = [r(Ci) * 0.5 + 1.0 for _ in range(2)], [r(Ci) * 0.3 for _ in range(2)]
+    ws_ = [K.pack_weights(r(3, 3, Ci, Co) / (9 * Ci) ** 0.5, Ci, Co, dt) for _ in range(2)]
+    bs = [r(Co), r(Co)]
+    # reference: finalize + apply (ReLU), then the conv with its statistics epilogue
+    a_ref, st_ref = K.instnorm_fwd_partial(x_raw, part, gam[0], bet[0], None, 1e-3, A.ACT_RELU, 0.0)
+    y_ref, p_ref = K.conv_fwd_stats(g, a_ref, ws_[0][0], bs[0])
+    stats = K.instnorm_finalize(part, H * W, 1e-3)
+    assert torch.equal(stats, st_ref)
+    a1, y, p = K.conv_fwd_stats_normload(g, x_raw, stats, gam[0], bet[0], ws_[0][0], bs[0])
+    assert torch.equal(a1, a_ref), "normalised operand"
+    assert torch.equal(y, y_ref), "conv output"
+    assert torch.equal(p, p_ref), "statistics rows"
+    if N >= 2 and g.pair_ok:
+        ns = N // 2
+        a_ref2, _ = K.instnorm_fwd_partial_pair(x_raw, part, gam[0], bet[0], gam[1], bet[1], ns, None, 1e-3, A.ACT_RELU, 0.0)
+        y_ref2, p_ref2 = K.conv_fwd_stats_pair(g, a_ref2, ws_[0][0], bs[0], ws_[1][0], bs[1], ns)
+        a2, y2, p2 = K.conv_fwd_stats_normload(g, x_raw, stats, gam[0], bet[0], ws_[0][0], bs[0], pair=(gam[1], bet[1], ws_[1][0], bs[1], ns))
+        assert torch.equal(a2, a_ref2) and torch.equal(y2, y_ref2) and torch.equal(p2, p_ref2), "pair"
+
+
+@pytest.mark.gpu
+def test_halo_kernels_with_operands_in_the_upper_half_of_a_4gib_window(sg):
+    """The 3x3 halo kernels address their LDS-DMA sources as a uniform 64-bit base (SGPR pair, assembled from two
+    v_readfirstlane halves) + a 32-bit lane offset.  Regression test for the sign extension of the low half: operands whose
+    address has bit 31 set (the upper 2 GiB of every 4 GiB window) must give the same results as anywhere else."""
+    from sggan_amd import kernels as K
+    N, H, W, Cc = 2, 8, 128, 64
+    dt = torch.bfloat16
+    g = K.conv_geom(N, H, W, Cc, Cc, 3, 3, 1, "VALID", 1, dt)
+    gen = torch.Generator().manual_seed(5)
+    r = lambda *sh: torch.randn(sh, generator=gen).cuda()
+    x, dy = r(N, H, W, Cc).to(dt), r(N, H, W, Cc).to(dt)
+    wf, wd = K.pack_weights(r(3, 3, Cc, Cc) / 24.0, Cc, Cc, dt)
+    bias = r(Cc)
+    y_ref, dx_ref = K.conv_fwd(g, x, wf, bias), K.conv_dgrad(g, dy, wd)
+    arena = torch.empty((1 << 32) + (1 << 28), dtype=torch.uint8, device="cuda")      # spans a whole 4 GiB window
+    base = arena.data_ptr()
+    first = (base >> 32 << 32) + 0x80001000                                            # low 32 address bits = 0x80001000
+    off = (first if first >= base else first + (1 << 32)) - base
+    assert 0 <= off and off + (64 << 20) < arena.numel()
+
+    def place(t):
+        nonlocal off
+        nb = t.numel() * t.element_size()
+        v = arena[off:off + nb].view(t.dtype).reshape(t.shape)
+        v.copy_(t)
+        assert (v.data_ptr() & 0xffffffff) >= (1 << 31)
+        off += (nb + 255) // 256 * 256
+        return v
+
+    xh, dyh, wfh, wdh = place(x), place(dy), place(wf), place(wd)
+    assert torch.equal(K.conv_fwd(g, xh, wfh, bias), y_ref)
+    assert torch.equal(K.conv_dgrad(g, dyh, wdh), dx_ref)

@@ -12,7 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=8); ap.add_argument("--h", type=int, default=64); ap.add_argument("--w", type=int, default=128)
 ap.add_argument("--c", type=int, default=256); ap.add_argument("--k", type=int, default=256); ap.add_argument("--r", type=int, default=3)
 ap.add_argument("--stride", type=int, default=1); ap.add_argument("--pad", default="REFLECT-1")
-ap.add_argument("--iters", type=int, default=50); ap.add_argument("--ops", default="fwd,dgrad,wgrad"); ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--iters", type=int, default=50); ap.add_argument("--ops", default="fwd,dgrad,wgrad"); ap.add_argument("--dtype", default="bf16"); ap.add_argument("--rounds", type=int, default=1)
 a = ap.parse_args()
 dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 pad, refl = ("VALID", int(a.pad.split("-")[1])) if a.pad.startswith("REFLECT") else (a.pad, 0)
@@ -36,7 +36,7 @@ if "dgrad_stats" in a.ops or "in_partial" in a.ops:      # data gradient + the n
     dxs, part = K.conv_dgrad_stats(g, dy, wd, x, nx, nst, gam, bet, AB.ACT_RELU, 0.0)
     fns["in_bwd"] = lambda: K.instnorm_bwd(dxs, nx, gam, bet, nst, dgm, dbt, False, AB.ACT_RELU)
     fns["in_bwd_partial"] = lambda: K.instnorm_bwd_partial(dxs, nx, part, gam, bet, nst, dgm, dbt, False, AB.ACT_RELU)
-if any(o in a.ops.split(",") for o in ("fwd_pair", "dgrad_pair", "wgrad_pair2")):
+if any(o in a.ops.split(",") for o in ("fwd_pair", "dgrad_pair", "wgrad_pair2", "fwd_normload_pair", "in_apply_pair", "fwd_stats", "fwd_normload", "in_apply")):
     # the launches the paired cycle step makes: a stacked batch of two networks (images [:n/2] / [n/2:]) with two weight sets
     assert a.n % 2 == 0
     h = a.n // 2
@@ -45,6 +45,18 @@ if any(o in a.ops.split(",") for o in ("fwd_pair", "dgrad_pair", "wgrad_pair2"))
     bias = torch.zeros(Kp, device="cuda")
     fns["fwd_pair"] = lambda: K.conv_fwd_stats_pair(g, x, wf, bias, wf2, bias, h)
     fns["dgrad_pair"] = lambda: K.conv_dgrad_pair(g, dy, wd, wd2, h, x)                      # + the skip-gradient addend, as in the step
+    # normalise-on-load: [finalize + apply pass] + conv  vs  finalize + the conv that applies the norm to its operand tiles
+    from sggan_amd import _abi as AB
+    gam, bet = torch.rand(Cp, device="cuda") + 0.5, torch.randn(Cp, device="cuda") * 0.1
+    xf = x.float().reshape(a.n, 4, a.h * a.w // 4, Cp)
+    part = torch.stack([xf.sum(2), (xf * xf).sum(2)], dim=-1).contiguous()
+    nstats = K.instnorm_finalize(part, a.h * a.w, 1e-3)
+    fns["in_apply_pair"] = lambda: K.instnorm_fwd_partial_pair(x, part, gam, bet, gam, bet, h, None, 1e-3, AB.ACT_RELU, 0.0)
+    fns["in_apply"] = lambda: K.instnorm_fwd_partial(x, part, gam, bet, None, 1e-3, AB.ACT_RELU, 0.0)
+    fns["in_finalize"] = lambda: K.instnorm_finalize(part, a.h * a.w, 1e-3)
+    fns["fwd_stats"] = lambda: K.conv_fwd_stats(g, x, wf, bias)
+    fns["fwd_normload"] = lambda: K.conv_fwd_stats_normload(g, x, nstats, gam, bet, wf, bias)
+    fns["fwd_normload_pair"] = lambda: K.conv_fwd_stats_normload(g, x, nstats, gam, bet, wf, bias, pair=(gam, bet, wf2, bias, h))
     gh = K.conv_geom(h, a.h, a.w, Cp, Kp, a.r, a.r, a.stride, pad, refl, dt)
     xs = [torch.randn(gh.x_shape, device="cuda").to(dt) for _ in range(4)]
     ds = [torch.randn(gh.y_shape, device="cuda").to(dt) for _ in range(4)]
@@ -53,16 +65,27 @@ if any(o in a.ops.split(",") for o in ("fwd_pair", "dgrad_pair", "wgrad_pair2"))
     FLOPS = {"wgrad_pair2": 4 * 2.0 * gh.y_shape[0] * gh.y_shape[1] * gh.y_shape[2] * a.k * a.r * a.r * a.c}
 else:
     FLOPS = {}
-for op in a.ops.split(","):
-    f = fns[op]
-    for _ in range(5):
-        f()
-    torch.cuda.synchronize()
+def timed(f, iters):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(a.iters):
+    for _ in range(iters):
         f()
     e.record(); torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / a.iters
+    return s.elapsed_time(e) / iters
+
+
+ops = a.ops.split(",")
+for op in ops:
+    for _ in range(5):
+        fns[op]()
+torch.cuda.synchronize()
+# --rounds R: the ops are timed round-robin R times and the median per op is printed (the clocks move with what ran before:
+# an op timed first in a fresh process and the same op timed after others differ by up to 10 %)
+res = {op: [] for op in ops}
+for _ in range(a.rounds):
+    for op in ops:
+        res[op].append(timed(fns[op], a.iters))
+for op in ops:
+    ms = sorted(res[op])[len(res[op]) // 2]
     fl = FLOPS.get(op, flops)
-    print(f"{op:6s} {ms*1e3:8.1f} us  {fl/ms/1e9:8.1f} TFLOP/s  ({fl/1e9:.1f} GFLOP)", flush=True)
+    print(f"{op:18s} {ms*1e3:8.1f} us  {fl/ms/1e9:8.1f} TFLOP/s  ({fl/1e9:.1f} GFLOP)  [min {min(res[op])*1e3:.1f}, max {max(res[op])*1e3:.1f}, {a.rounds} x {a.iters}]", flush=True)

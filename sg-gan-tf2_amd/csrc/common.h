@@ -141,6 +141,29 @@ __device__ inline void dma16_to_lds_s(const void* sbase, uint32_t voff, __attrib
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(m) : "memory", "m0");
 }
 
+// ... and through a buffer descriptor: `buffer_load_dwordx4 voff, rsrc, soff offen lds`.  The address is base + soff + voff
+// with base / size in four SGPRs for the whole kernel, so a piece costs NO vector instruction -- the scalar part of the
+// address goes in soff -- and lanes whose voff is outside the buffer write ZEROS to LDS (checked on gfx950 with
+// tools/probes/bufload_lds.hip): zero padding needs no select against a zero page and no per-piece lane mask.  The range
+// check is documented for voff (+ the immediate); callers keep voff alone either inside the buffer or >= SGG_BUF_OOB with
+// the buffer smaller than that, so the result is the same whether or not the hardware adds soff before checking.
+typedef int sgg_rsrc_t __attribute__((ext_vector_type(4)));
+#define SGG_BUF_OOB 0x40000000u
+__device__ inline sgg_rsrc_t sgg_make_rsrc(const void* base, uint32_t bytes) {
+    const uint64_t b = (uint64_t)(uintptr_t)base;
+    sgg_rsrc_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xffffu));     // stride 0, no swizzle
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;                                                              // raw 32-bit data format
+    return r;
+}
+__device__ inline void dma16_buf_to_lds(uint32_t voff, sgg_rsrc_t rsrc, uint32_t soff, __attribute__((address_space(3))) void* lds_wave_base) {
+    const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave_base);
+    const uint32_t so = __builtin_amdgcn_readfirstlane(soff);
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(so), "s"(m) : "memory", "m0");
+}
+
 __device__ inline void dma4_to_lds(const void* gsrc, __attribute__((address_space(3))) void* lds_wave_base) {   // 4 bytes per lane at m0 + 4 * lane
     const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave_base);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(m) : "memory", "m0");

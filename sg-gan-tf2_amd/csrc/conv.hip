@@ -751,8 +751,17 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a_in) 
 #ifndef H3_NORM_AT
 #define H3_NORM_AT 1                                   // NORM: after which MFMA group of the step (0..3) the row transform runs
 #endif
-#ifndef H3_VADDR
-#define H3_VADDR 0                                     // 1: every DMA with a 64-bit per-lane address (the round-2 form; A/B switch)
+// DMA addressing of the halo kernel per source-padding mode (SRC 0 / 1 / 2): 0 = a 64-bit address per lane and piece,
+// 1 = uniform base in an SGPR pair + 32-bit lane offset, 2 = buffer descriptor (out-of-range lanes read zeros).  All three give
+// the same bits (tests/test_gpu_exact.py passes with each); the defaults are what measured fastest in the step.
+#ifndef H3_ADDR0
+#define H3_ADDR0 0
+#endif
+#ifndef H3_ADDR1
+#define H3_ADDR1 0
+#endif
+#ifndef H3_ADDR2
+#define H3_ADDR2 1
 #endif
 #ifndef H3_NORM_ABL
 #define H3_NORM_ABL 0                                  // timing experiments only (wrong results): 1 no store of the normalised rows, 2 no in-loop transform, 4 no prologue transform
@@ -828,14 +837,30 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     // ---- halo DMA: one wave-instruction = 8 halo pixels x 128 B; a halo row is 17 of them (wave, wave+8, wave+16)
     const int hpos = lane & 7, hsub = lane >> 3;
     constexpr bool mirror = SRC != 0;                                      // (the data gradient always zero-pads dy)
-    // DMA addressing: a 64-bit per-lane address per piece (zero-padded sources select against the zero page).  The other form
-    // -- a uniform base in an SGPR pair + a 32-bit lane offset, possible for REFLECT sources, where every halo pixel is an image
-    // pixel, and for the weight tiles -- frees ~16 VGPRs but costs SALU work and a scalar branch per piece on the issuer waves:
-    // in the step the paired forward ran at 0.484 of peak with it against 0.495 without, and the paired data gradient (weight
-    // tiles only) at 0.415 against 0.451 (profiles/r03_ab_dma_addressing.txt).  Only the normalise-on-load variant uses it: it
-    // needs the registers.  (What did pay is the padding mode as a template parameter: 0.472 -> 0.495.)
-    constexpr bool SADDR = SRC == 2 && !H3_VADDR;
+    // DMA addressing (ADDR), three forms measured against each other in the step (profiles/r03_ab_dma_addressing.txt):
+    // 0 -- a 64-bit address per lane and piece; zero-padded sources select against the zero page.  ~12 instructions per piece on
+    //      the issuer waves, and hipcc keeps every piece's lane mask (an SGPR pair) and base (a VGPR pair) live across the main
+    //      loop: ~90 SGPRs parked in VGPR lanes in the data gradient, ~50 v_readlane per step to get them back.
+    // 1 -- a uniform base in an SGPR pair + a 32-bit lane offset (REFLECT sources / weight tiles): ~16 VGPRs fewer.
+    // 2 -- buffer descriptors: base and size in four SGPRs per operand, the scalar part of a piece's address in the
+    //      instruction's soffset, the lane part one loop-invariant VGPR per piece position, lanes outside the buffer read ZEROS:
+    //      no zero page, no masks, no vector instruction per piece (issue part of a step: 201 -> 29 VALU, no v_readlane).
+    // Form 0 is the FASTEST: paired forward 0.495 of peak against 0.484 (form 1) and 0.473 -> 0.454 (form 2, another box);
+    // paired data gradient 0.451 against 0.415 (form 1 for the weight tiles) and 0.434 -> 0.422 (form 2).  An LDS-DMA piece
+    // costs the issuing wave 60-180 cycles whatever surrounds it (the CU's vector-memory path into LDS), so the address
+    // arithmetic of form 0 runs in time the wave would wait anyway, and the denser issue of forms 1 / 2 only bunches the LDS
+    // writes against the other waves' fragment reads.  Only the normalise-on-load variant uses form 1: it needs the registers.
+    // (What did pay is the padding mode as a template parameter: 0.472 -> 0.495.)
+    constexpr int ADDR = SRC == 0 ? H3_ADDR0 : (SRC == 1 ? H3_ADDR1 : H3_ADDR2);
+    static_assert(ADDR != 1 || SRC != 0, "the SGPR-base form has no zero padding");
+    constexpr bool SADDR = ADDR == 1, BUFA = ADDR == 2;
     const char* vrows = FOLD ? a.fold + (size_t)a.N * a.H * 18 * SC * 2 : nullptr;   // [N][2][W][SC] after the patches
+    const uint32_t rowbytes = (uint32_t)(a.W * SC * 2);
+    sgg_rsrc_t rsS, rsV, rsW;                              // this image of the source, its two virtual rows (FOLD), this tile's weight rows
+    if constexpr (BUFA) {
+        rsS = sgg_make_rsrc(a.src + (size_t)img * a.H * rowbytes, (uint32_t)a.H * rowbytes);
+        rsV = sgg_make_rsrc(FOLD ? vrows + (size_t)img * 2 * rowbytes : a.src, FOLD ? 2 * rowbytes : 0u);
+    }
     // (Walking the channel chunks in a per-block rotated order -- so that the blocks of one XCD do not all want the
     // same weight tile at the same moment -- measured 1-2 % slower: first-touch L2 misses are not what the tiles wait for.)
     // (vw, nw): this wave acts as issuer vw of nw -- all 8 waves in the prologue, 4 issuer waves in the main loop
@@ -845,13 +870,22 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         if (mirror) hi = hi < 0 ? -hi : (hi >= a.H ? 2 * (a.H - 1) - hi : hi);
         else rowok = (unsigned)hi < (unsigned)a.H;
         const char* rowp = a.src + ((size_t)img * a.H + (rowok ? hi : 0)) * a.W * SC * 2 + chunk * 128;
+        // BUFA: the row's descriptor and scalar offset -- the image, one of the two virtual rows (FOLD), or an EMPTY buffer for a
+        // row above / below the image (every lane out of range: zeros) -- so that each piece is the same single instruction
+        sgg_rsrc_t rs = rsS;
+        uint32_t soff = (uint32_t)(rowok ? hi : 0) * rowbytes + chunk * 128;
         if (FOLD) {
-            if (h0 == 0 && k == 3) rowp = vrows + ((size_t)img * 2 + 0) * a.W * SC * 2 + chunk * 128;
-            if (h0 == a.H - 2 && k == 0) rowp = vrows + ((size_t)img * 2 + 1) * a.W * SC * 2 + chunk * 128;
+            if (h0 == 0 && k == 3) { rowp = vrows + ((size_t)img * 2 + 0) * a.W * SC * 2 + chunk * 128; rs = rsV; soff = chunk * 128; }
+            if (h0 == a.H - 2 && k == 0) { rowp = vrows + ((size_t)img * 2 + 1) * a.W * SC * 2 + chunk * 128; rs = rsV; soff = rowbytes + chunk * 128; }
         }
+        if (!rowok) rs[2] = 0;
+        // (the issuer index once more through an opaque asm, for the SCALAR parts of a piece -- LDS destination, soffset: as
+        // loop invariants hipcc parks them in VGPR lanes, 90 spilled SGPRs and ~50 v_readlane per step in the data gradient)
+        int vws = vw;
+        if (BUFA) asm volatile("" : "+s"(vws));
 #pragma unroll
         for (int qi = 0; qi < 5; ++qi) {
-            const int q = vw + nw * qi;
+            const int q = vw + nw * qi, qs = vws + nw * qi;
             if (q >= 17) break;
             const int hp = q * 8 + hsub;                                   // halo column 0..135
             int wi = w0 - 1 + hp;
@@ -868,13 +902,18 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             // address: position hpos of row r holds chunk (hpos - (r & 6)) & 7.
             const int hrow_ = k * H3_PITCH + hp;
             const int schunk = H3_ROT ? ((hpos - (hrow_ & 6)) & 7) : (hpos ^ ((hrow_ >> 1) & 7));
-            if (SADDR) {
-                // every halo pixel is an image pixel (the six filler columns of the pitch read mirrored pixels nobody uses):
-                // uniform row base + a 32-bit lane offset
-                dma16_to_lds_s(rowp, (uint32_t)(wi * SC * 2 + (schunk << 4)), (__attribute__((address_space(3))) void*)(lH + (k * H3_PITCH + q * 8) * 128));
+            __attribute__((address_space(3))) void* const ldst = (__attribute__((address_space(3))) void*)(lH + (k * H3_PITCH + qs * 8) * 128);
+            if (BUFA) {
+                // lane part: a loop invariant per piece position (H3_PITCH is a multiple of 8: the rotation does not depend on k);
+                // REFLECT: every halo pixel is an image pixel (the six filler columns read mirrored pixels nobody uses)
+                const bool colok = mirror || (hp < H3_TW + 2 && (unsigned)wi < (unsigned)a.W);
+                const uint32_t voff = colok ? (uint32_t)(wi * SC * 2 + (schunk << 4)) : SGG_BUF_OOB;
+                dma16_buf_to_lds(voff, rs, soff, ldst);
+            } else if (SADDR) {
+                dma16_to_lds_s(rowp, (uint32_t)(wi * SC * 2 + (schunk << 4)), ldst);
             } else {
                 const char* src = ok ? rowp + (size_t)wi * SC * 2 + (schunk << 4) : zero;
-                dma16_to_lds(src, (__attribute__((address_space(3))) void*)(lH + (k * H3_PITCH + q * 8) * 128));
+                dma16_to_lds(src, ldst);
             }
         }
     };
@@ -900,26 +939,35 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
 
     // ---- weight-tile DMA: 32 wave-instructions of 8 rows x 128 B per tile; instruction d covers rows 8d .. 8d+7, lane l row
     // 8d + l/8 at chunk position l%8 (swizzled by the row: key = (l/16 + 4(d&1)) & 7, i.e. the d-even key with bit 2 flipped)
-    // Addressing: a uniform base per instruction (tile column, 8-row group, tap, chunk: SGPR arithmetic) + ONE per-lane offset
-    // for the whole kernel (row within the group and the swizzled chunk; d & 1 == vw & 1 because nw is even).  DC is a
-    // multiple of 8, so an 8-row group is inside the matrix or outside it as a whole: a scalar test.
+    // One per-lane offset for the whole kernel (row within the 8-row group and the swizzled chunk; d & 1 == vw & 1 because nw is
+    // even); DC is a multiple of 8, so an 8-row group is inside the matrix or outside it as a whole: a scalar test.
     const int wl = lane >> 3;
     const int wsw = ((lane & 7) ^ ((lane >> 4) & 7)) << 4;
     const uint32_t wvoff0 = (uint32_t)(wl * wrow * 2 + wsw), wvoff1 = (uint32_t)(wl * wrow * 2 + (wsw ^ 64));
+    if constexpr (BUFA) rsW = sgg_make_rsrc(wmat_n + (size_t)n0 * wrow * 2, (uint32_t)((DC - n0 < BN ? DC - n0 : BN) * wrow * 2));
     auto load_w = [&](int stg, int chunk, int tap, int vw, int nw) {
         const char* const tbase = wmat_n + ((size_t)n0 * wrow + tap * SC + chunk * 64) * 2;
         const uint32_t wvoff = (vw & 1) ? wvoff1 : wvoff0;
         lds_char* sQ = lB + stg * (256 * 128);
+        int vws = vw;
+        if (BUFA) asm volatile("" : "+s"(vws));          // (see load_halo_row)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int d = vw + nw * j;
+            const int d = vw + nw * j, ds = vws + nw * j;
             if (d >= 32) break;
-            if (!SADDR) {
+            __attribute__((address_space(3))) void* const ldst = (__attribute__((address_space(3))) void*)(sQ + ds * 8 * 128);
+            if (BUFA) {
+                // rows past DC: the descriptor ends at the matrix (or at the tile), and so that the outcome does not hang on how
+                // the range check treats soffset, such a group is asked for with an out-of-range LANE offset
+                const uint32_t so = (uint32_t)(ds * 8 * wrow * 2 + (tap * SC + chunk * 64) * 2);
+                if (n0 + ds * 8 < DC) dma16_buf_to_lds(wvoff, rsW, so, ldst);
+                else dma16_buf_to_lds(SGG_BUF_OOB, rsW, 0u, ldst);
+            } else if (!SADDR) {
                 const bool ok = n0 + d * 8 + wl < DC;
                 const char* src = ok ? wmat_n + (size_t)(n0 + wl) * wrow * 2 + d * ((size_t)8 * wrow * 2) + (tap * SC + chunk * 64) * 2 + (wsw ^ ((d & 1) << 6)) : zero;
-                dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sQ + d * 8 * 128));
-            } else if (n0 + d * 8 < DC) dma16_to_lds_s(tbase + (size_t)d * 8 * wrow * 2, wvoff, (__attribute__((address_space(3))) void*)(sQ + d * 8 * 128));
-            else dma16_to_lds(zero, (__attribute__((address_space(3))) void*)(sQ + d * 8 * 128));
+                dma16_to_lds(src, ldst);
+            } else if (n0 + d * 8 < DC) dma16_to_lds_s(tbase + (size_t)d * 8 * wrow * 2, wvoff, ldst);
+            else dma16_to_lds(zero, ldst);
         }
     };
 
@@ -1583,6 +1631,8 @@ static bool halo3_ok(const ConvArgs& a, int mode, bool is_bf16) {
     if (a.W % H3_TW || (a.H & 1) || a.H < 4) return false;
     const int SC = mode == MODE_FWD ? a.C : a.K;
     if (SC % 64) return false;
+    // buffer-descriptor DMAs: one image of the source and one tile's weight rows must stay below SGG_BUF_OOB bytes
+    if ((int64_t)a.H * a.W * SC * 2 >= (int64_t)SGG_BUF_OOB || (int64_t)256 * 9 * SC * 2 >= (int64_t)SGG_BUF_OOB) return false;
     return mode == MODE_FWD || mode == MODE_DGRAD;
 }
 

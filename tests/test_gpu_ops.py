@@ -649,3 +649,10 @@ def test_halo_kernels_with_operands_in_the_upper_half_of_a_4gib_window(sg):
     xh, dyh, wfh, wdh = place(x), place(dy), place(wf), place(wd)
     assert torch.equal(K.conv_fwd(g, xh, wfh, bias), y_ref)
     assert torch.equal(K.conv_dgrad(g, dyh, wdh), dx_ref)
+    # the normalise-on-load variant is the one kernel that uses the SGPR-pair form
+    xf = x.float().reshape(N, 2, H * W // 2, Cc)
+    stats = K.instnorm_finalize(torch.stack([xf.sum(2), (xf * xf).sum(2)], dim=-1).contiguous(), H * W, 1e-3)
+    gam, bet = r(Cc) * 0.5 + 1.0, r(Cc) * 0.3
+    ref = K.conv_fwd_stats_normload(g, x, stats, gam, bet, wf, bias)
+    got = K.conv_fwd_stats_normload(g, xh, stats, gam, bet, wfh, bias)
+    assert all(torch.equal(u, v) for u, v in zip(got, ref))

@@ -2017,6 +2017,9 @@ __global__ __launch_bounds__(256) void pad3_fold_kernel(const f32x4* dxp, char* 
 // while the other 10 are in use.  Both operands are read with the transposing ds_read_b64_tr_b16 (pixels are the
 // reduction index).  One f32 slab [7][64][32] per block; wgrad7_reduce_kernel sums them in fixed order.
 // -------------------------------------------------------------------------------------------------
+#ifndef W7_INTERLEAVE
+#define W7_INTERLEAVE 1                                // the main loop's A-row DMAs between the MFMA batches (0: all at the head of the step)
+#endif
 #define W7_TW 58                                        // strip width in pixels of B's grid (58 + 6 = 64 = two k-steps)
 #define W7_AROW (64 * 128)                              // bytes per A row (64 pixels x 64 channels)
 #define W7_BSROW (64 * 64)                              // bytes per Bs row (64 pixels x 32 columns)
@@ -2063,8 +2066,8 @@ __global__ __launch_bounds__(512) void wgrad7_kernel(W7Args a) {
     // ---- A rows: ring row k (k = 0 .. rows + 5) is image row yb + k - pa; 8 DMA instructions of 8 pixels per row.
     // Rows k0 .. k0+nrows-1; instruction ids are dealt round-robin to the issuing waves.  Rows past the image read the zero page.
     const int hsub = lane >> 3, hpos = lane & 7;
-    auto load_a_rows = [&](int k0, int nrows, int vw, int nw) {          // this wave acts as issuer vw of nw
-        for (int id = vw; id < nrows * 8; id += nw) {
+    auto load_a_rows = [&](int k0, int nrows, int vw, int nw, int j0 = 0, int j1 = 1 << 20) {   // this wave acts as issuer vw of nw; its pieces [j0, j1)
+        for (int id = vw + nw * j0, j = j0; id < nrows * 8 && j < j1; id += nw, ++j) {
             const int k = k0 + (id >> 3), i = id & 7;
             const int q = i * 8 + hsub;
             int yi = yb + k - a.pa, xi = x0 - a.pa + q;
@@ -2164,7 +2167,7 @@ __global__ __launch_bounds__(512) void wgrad7_kernel(W7Args a) {
     for (int t = 0; t < nsteps; ++t) {
         // rows of step t + PD into the slots step t - 1 released, by waves 0..5 (always issued: rows past the segment are
         // harmless and keep every issuer's count of outstanding DMAs per step constant)
-        if (wave < Cfg::NISS && SGG_ABLATE_OF(a) != 3) load_a_rows(RS + 6 + (t + PD - 1) * RS, RS, wave, Cfg::NISS);
+        if (!W7_INTERLEAVE && wave < Cfg::NISS && SGG_ABLATE_OF(a) != 3) load_a_rows(RS + 6 + (t + PD - 1) * RS, RS, wave, Cfg::NISS);
         if (wave < 7 && SGG_ABLATE_OF(a) == 1) {
         } else if (wave < 7) {
             const int r = wave;
@@ -2200,6 +2203,13 @@ __global__ __launch_bounds__(512) void wgrad7_kernel(W7Args a) {
                     for (int jt = 0; jt < 2; ++jt) acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[jt], acc[it][jt], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                // the A-row DMAs of step t + PD, ONE piece per issuer wave after each of its first MFMA batches instead of all of
+                // them at the head of the step: a piece costs its wave 60-180 cycles of issue, which now fall under the SIMD
+                // partner's MFMAs (with all six issuers at the head of the step the matrix pipes idled for that long every step)
+                if (W7_INTERLEAVE && bi < Cfg::A_PER_WAVE && wave < Cfg::NISS && SGG_ABLATE_OF(a) != 3) {
+                    load_a_rows(RS + 6 + (t + PD - 1) * RS, RS, wave, Cfg::NISS, bi, bi + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             // the rows of step t+1 (issued PD-1 steps ago) have landed; the later steps' may still be in flight
             if (wave < Cfg::NISS) w7_wait_vm<Cfg::A_PER_WAVE * (PD - 1)>();

@@ -2345,6 +2345,109 @@ static int run_w7(const sgg_conv_desc* d, bool stem, const void* x, const void* 
 }
 
 // head forward: 7x7 stride 1, 64 -> <= 3 channels (stored in 8), bf16, same-size output
+// -------------------------------------------------------------------------------------------------
+// Data gradient of the discriminator's first conv (module.py:284: 3x3, stride 2, SAME, 3(8) -> 64 channels): dx has 8 channels,
+// dy 64.  As an implicit GEMM (conv_gemm_glds_kernel<DGRAD, 256x16>) the layer ran at 11 TFLOP/s, 162 us for both discriminators'
+// 16 images -- all of it gather overhead: the work is 0.45 GMAC against 50 MB of traffic (~10 us).  Here a wave owns two dx rows
+// (2m, 2m+1) x 32 columns (both column parities of 16 column pairs j): with even H, W (TF 'SAME' pads bottom / right only) the
+// stride-2 taps that reach them are
+//     row 2m  : r = 0 from dy row m,  r = 2 from dy row m-1        column 2j  : s = 0 from dy column j,  s = 2 from column j-1
+//     row 2m+1: r = 1 from dy row m                                 column 2j+1: s = 1 from dy column j
+// i.e. four fragments of 16 dy pixels (rows m-1 / m, columns j-1.. / j..), loaded straight from global memory in the MFMA operand
+// layout (a pixel's 64 channels are the reduction: 2 k-steps), feed 9 tap products: D[channel][pixel] += W_tap[channel][k] dy[k][pixel].
+// The 9 x 2 weight fragments stay in registers while a wave walks its share of the work items.  No LDS, no barrier.
+// Two networks on one stacked batch: images >= nsplit take w2.
+// -------------------------------------------------------------------------------------------------
+struct S2NArgs {
+    const char* dy;      // (N,Ho,Wo,64) bf16
+    const char* w;       // w_dgrad [8][9*64] bf16 (rows = dx channels)
+    const char* w2;
+    char* dx;            // (N,H,W,8) bf16
+    int N, nsplit, H, W, Ho, Wo, items, items_per_wave;
+};
+
+__global__ __launch_bounds__(256) void conv3x3s2_narrow_dgrad_kernel(S2NArgs a) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int frow = lane & 15, fq = lane >> 4;
+    const int gw = blockIdx.x * 4 + wave;
+    const int it0 = gw * a.items_per_wave, it1 = min(a.items, it0 + a.items_per_wave);
+    const int jblocks = (a.Wo + 15) >> 4, mrows = a.Ho;
+    int cur_net = -1;
+    u32x4 wr[9][2];
+    for (int it = it0; it < it1; ++it) {
+        int b = it;
+        const int jb = b % jblocks; b /= jblocks;
+        const int m = b % mrows;
+        const int n = b / mrows;
+        const int net = n >= a.nsplit ? 1 : 0;
+        if (net != cur_net) {                               // (a wave's items are consecutive: at most one switch)
+            cur_net = net;
+            const char* wm = net ? a.w2 : a.w;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    wr[t][kk] = frow < 8 ? ld16(wm + (((size_t)frow * 9 + t) * 64 + kk * 32 + fq * 8) * 2) : zero16();
+        }
+        // dy fragments: [row m-1 / m][column shift -1 / 0][k-step]
+        u32x4 fy[2][2][2];
+        const int j = jb * 16 + frow;
+#pragma unroll
+        for (int ry = 0; ry < 2; ++ry)
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                const int yo = m - 1 + ry, xo = j - 1 + sx;
+                const bool ok = yo >= 0 && (unsigned)xo < (unsigned)a.Wo;
+                const char* src = a.dy + ((((size_t)n * a.Ho + (ok ? yo : 0)) * a.Wo + (ok ? xo : 0)) * 64 + fq * 8) * 2;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fy[ry][sx][kk] = ok ? ld16(src + kk * 64) : zero16();
+            }
+        f32x4 acc[2][2];                                    // [dx row parity][dx column parity]
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) acc[py][px] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto mac = [&](int py, int px, int r, int sx_tap, int ry, int sx) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                acc[py][px] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr[r * 3 + sx_tap][kk]),
+                                                                      __builtin_bit_cast(bf16x8, fy[ry][sx][kk]), acc[py][px], 0, 0, 0);
+        };
+        // (dx row parity, dx column parity) <- tap (r, s) from fragment (dy row m-1+ry, column shift sx); fixed order
+        mac(0, 0, 0, 0, 1, 1); mac(0, 0, 0, 2, 1, 0); mac(0, 0, 2, 0, 0, 1); mac(0, 0, 2, 2, 0, 0);
+        mac(0, 1, 0, 1, 1, 1); mac(0, 1, 2, 1, 0, 1);
+        mac(1, 0, 1, 0, 1, 1); mac(1, 0, 1, 2, 1, 0);
+        mac(1, 1, 1, 1, 1, 1);
+        // D[channel = 4 fq + e][pixel = frow]: lanes fq < 2 hold the 8 channels of column pair j
+        if (fq < 2 && j < a.Wo) {
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    const f32x4 v = acc[py][px];
+                    const bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    *reinterpret_cast<bf16x4*>(a.dx + ((((size_t)n * a.H + 2 * m + py) * a.W + 2 * j + px) * 8 + fq * 4) * 2) = pk;
+                }
+        }
+    }
+}
+
+static bool s2n_dgrad_ok(const sgg_conv_desc* d) {
+    return use_glds() && d->dtype == SGG_BF16 && d->pad_mode == SGG_PAD_ZERO && d->R == 3 && d->S == 3 && d->stride == 2 && d->C == 8 && d->K == 64 &&
+           d->pad_t == 0 && d->pad_l == 0 && d->H == 2 * d->Ho && d->W == 2 * d->Wo;
+}
+static int launch_s2n_dgrad(const sgg_conv_desc* d, const void* dy, const void* w, const void* w2, int nsplit, void* dx, hipStream_t s) {
+    S2NArgs q;
+    q.dy = (const char*)dy; q.w = (const char*)w; q.w2 = (const char*)(w2 ? w2 : w); q.dx = (char*)dx;
+    q.N = d->N; q.nsplit = w2 ? nsplit : d->N; q.H = d->H; q.W = d->W; q.Ho = d->Ho; q.Wo = d->Wo;
+    q.items = d->N * d->Ho * ((d->Wo + 15) / 16);
+    const int waves = 256 * 16;                          // 16 waves per CU, each walking a contiguous run of items
+    q.items_per_wave = (q.items + waves - 1) / waves;
+    const int blocks = ((q.items + q.items_per_wave - 1) / q.items_per_wave + 3) / 4;
+    hipLaunchKernelGGL(conv3x3s2_narrow_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, q);
+    return sgg_check_launch();
+}
+
 static bool n7_fwd_ok(const sgg_conv_desc* d) {
     return sgg_config().n7 && d->dtype == SGG_BF16 && d->R == 7 && d->S == 7 && d->stride == 1 && d->C == 64 && d->K == 8 &&
            d->Ho == d->H && d->Wo == d->W && d->pad_t == 3 && d->pad_l == 3 && d->H >= 8 && d->W >= 8;
@@ -4084,6 +4187,7 @@ static int conv2d_bwd_data_impl(const sgg_conv_desc* d, const void* dy, const vo
         // REFLECT: add the mirrored (MirrorPadGrad) terms of the border pixels with the small register-path launch
         return d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_BORDER>(a, (hipStream_t)stream) : launch_gemm<float, MODE_BORDER>(a, (hipStream_t)stream);
     }
+    if (!addend && !nb && s2n_dgrad_ok(d)) return launch_s2n_dgrad(d, dy, w, nullptr, 0, dx, (hipStream_t)stream);
     if (!addend && !nb && use_glds() && n7_dgrad_ok(d)) {
         // the stem: data gradient on the PADDED grid (a zero-padded "full" correlation of dy with the mirrored taps, f32),
         // then MirrorPadGrad as a fold of the 3-pixel frame onto the image -- one rounding, no separate border GEMM
@@ -4237,6 +4341,11 @@ int sgg_conv2d_bwd_data_group2(const sgg_conv_desc* d, const void* dy, const voi
                                void* ws, size_t ws_bytes, void* stream) {
     if (!desc_ok(d) || !dy || !w || !w2 || !dx) return SGG_EINVAL;
     const size_t xin = tensor_bytes(d, false), yout = tensor_bytes(d, true);
+    if (!addend && s2n_dgrad_ok(d)) {                    // D.h0: one launch over the stacked batch, weights picked per image
+        sgg_conv_desc d2 = *d;
+        d2.N = 2 * d->N;
+        return launch_s2n_dgrad(&d2, dy, w, w2, d->N, dx, (hipStream_t)stream);
+    }
     const bool special = !use_glds() || (!addend && (halo_narrow_in_ok(d, d->K, d->C) || n7_dgrad_ok(d) || halo_dgrad_narrow_ok(d))) || fold_bytes(d) > 0;
     if (special) {                                       // (REFLECT shapes of the 3x3 halo kernel: sgg_conv2d_bwd_data_pair)
         int rc = sgg_conv2d_bwd_data(d, dy, w, addend, dx, ws, ws_bytes, stream);

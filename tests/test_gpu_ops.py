@@ -507,6 +507,7 @@ def test_timed_launch_hooks_put_events_on_the_kernel_dispatch(sg):
     ("D.h32-like: split-K tail", 2, 15, 31, 512, 512, 3, 2, "VALID", torch.bfloat16),
     ("D.h4-like: 34 output channels", 2, 5, 13, 512, 40, 3, 1, "SAME", torch.bfloat16),
     ("c2-like: stride-2 forward / stride-2 halo data gradient", 2, 64, 128, 64, 128, 3, 2, "SAME", torch.bfloat16),
+    ("h0-like: 8 -> 64 channels, stride 2 (the narrow stride-2 data-gradient kernel)", 2, 32, 80, 8, 64, 3, 2, "SAME", torch.bfloat16),
     ("h3-like: 256x256 tiles", 2, 32, 64, 256, 512, 3, 1, "SAME", torch.bfloat16),
     ("odd generic f32", 3, 9, 11, 16, 24, 3, 1, "SAME", torch.float32),
     ("3x3 stride-1 halo shape, zero padding", 2, 64, 128, 64, 64, 3, 1, "SAME", torch.bfloat16),

@@ -2448,6 +2448,169 @@ static int launch_s2n_dgrad(const sgg_conv_desc* d, const void* dy, const void* 
     return sgg_check_launch();
 }
 
+// -------------------------------------------------------------------------------------------------
+// Weight gradient of the same layer (D.h0: x has 3 real channels, dy 64): dW[r][s][c][k] = sum_pixels x[2yo+r][2xo+s][c] dy[yo][xo][k],
+// a 27 x 64 result over 262 144 pixels per 8 images.  As a GEMM the reduction runs over pixels, so both operands would have to be
+// transposed through LDS for 0.45 GMAC of work; the register-staged generic kernel (v1) ran it at 20 TFLOP/s, 46.6 us incl. 21 us
+// of slab reduce (now 28 + 5 us).  The work is
+// small enough for the vector ALU: a lane owns one output channel k and keeps the 9 x CR sums in registers; per output pixel it
+// reads its dy value (one 128-byte line per wave) and multiplies it with the pixel's 9 x CR input values, which every lane reads
+// from the SAME LDS address (a broadcast read) out of three input rows staged as float32.  A block walks (image, output row, half
+// row) units; its four waves split a unit's pixels, add up through LDS in fixed order at the end and write ONE slab per block.
+// -------------------------------------------------------------------------------------------------
+#define S2W_SEG 128                                     // output pixels per unit
+#define S2W_XPIX (2 * S2W_SEG + 2)                      // input pixels per staged row (+1 used, +1 pad)
+template <int CR>                                      // input channels computed (4: the first half of the padded 8)
+__global__ __launch_bounds__(256) void conv3x3s2_narrow_wgrad_kernel(const char* __restrict__ x, const char* __restrict__ dy, float* __restrict__ ws,
+                                                                     int N, int H, int W, int Ho, int Wo, int units, int units_per_block) {
+    constexpr int CV = CR <= 4 ? 4 : 8;                 // floats per staged pixel
+    // staging buffers and, after the last unit, the cross-wave reduction buffer share one allocation
+    constexpr int XB = 3 * S2W_XPIX * CV * 4, DB = S2W_SEG * 64 * 2, RB = 4 * 9 * CR * 64 * 4;
+    __shared__ __attribute__((aligned(16))) char sraw[(XB + DB > RB) ? (XB + DB) : RB];
+    float (*sX)[S2W_XPIX][CV] = reinterpret_cast<float (*)[S2W_XPIX][CV]>(sraw);
+    bf16 (*sD)[64] = reinterpret_cast<bf16 (*)[64]>(sraw + XB);
+    float (*sRed)[9 * CR][64] = reinterpret_cast<float (*)[9 * CR][64]>(sraw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int segs = (Wo + S2W_SEG - 1) / S2W_SEG;
+    float acc[9][CR];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < CR; ++c) acc[t][c] = 0.f;
+    const int u0 = blockIdx.x * units_per_block, u1 = min(units, u0 + units_per_block);
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    // a unit's operands travel global -> registers -> LDS; the NEXT unit's loads are issued before this unit's arithmetic
+    // (with the dy values read straight from global memory per pixel the kernel was latency bound: 91 us)
+    constexpr int XL = (3 * S2W_XPIX + 255) / 256, DL = S2W_SEG * 8 / 256;     // 16-byte pieces per thread
+    u32x4 rx[XL], rd[DL];
+    auto fetch = [&](int u) {
+        int b = u;
+        const int seg = b % segs; b /= segs;
+        const int yo = b % Ho;
+        const int n = b / Ho;
+        const int xo0 = seg * S2W_SEG, X0 = 2 * xo0;
+#pragma unroll
+        for (int l = 0; l < XL; ++l) {
+            const int i = tid + 256 * l;
+            const int r = i / S2W_XPIX, px = i - r * S2W_XPIX;
+            const int Y = 2 * yo + r, X = X0 + px;
+            // (a select between ADDRESSES, not a conditional load: that compiles to a branch with a full vmcnt(0) wait behind it)
+            const bool ok = i < 3 * S2W_XPIX && Y < H && X < W;                  // bottom / right padding: zeros
+            rx[l] = ld16(ok ? x + (((size_t)n * H + Y) * W + X) * 16 : zero);
+        }
+#pragma unroll
+        for (int l = 0; l < DL; ++l) {
+            const int i = tid + 256 * l, p = i >> 3, ch = i & 7;
+            rd[l] = ld16(xo0 + p < Wo ? dy + ((((size_t)n * Ho + yo) * Wo + xo0 + p) * 64 + ch * 8) * 2 : zero);
+        }
+    };
+    if (u0 < u1) fetch(u0);
+    for (int u = u0; u < u1; ++u) {
+        __syncthreads();                                // the previous unit's reads of sX / sD are done
+#pragma unroll
+        for (int l = 0; l < XL; ++l) {
+            const int i = tid + 256 * l;
+            if (i >= 3 * S2W_XPIX) continue;
+            const int r = i / S2W_XPIX, px = i - r * S2W_XPIX;
+            float v[8];
+            // (opaque to the optimiser until here: it otherwise converts each piece right behind its load in fetch() -- same
+            // register count -- and waits for vmcnt(0) there, four dependent round trips per unit instead of a prefetch)
+            asm volatile("" : "+v"(rx[l][0]), "+v"(rx[l][1]), "+v"(rx[l][2]), "+v"(rx[l][3]));
+            ET<bf16>::unpack(rx[l], v);
+#pragma unroll
+            for (int e = 0; e < CV; e += 4) *reinterpret_cast<f32x4*>(&sX[r][px][e]) = (f32x4){v[e], v[e + 1], v[e + 2], v[e + 3]};
+        }
+#pragma unroll
+        for (int l = 0; l < DL; ++l) {
+            const int i = tid + 256 * l;
+            st16(reinterpret_cast<char*>(&sD[0][0]) + i * 16, rd[l]);
+        }
+        __syncthreads();
+        if (u + 1 < u1) fetch(u + 1);
+        // this wave's quarter of the unit, four pixels per trip
+        const int p0 = wave * (S2W_SEG / 4);
+        for (int p = p0; p < p0 + S2W_SEG / 4; p += 4) {
+            uint16_t draw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) draw[q] = reinterpret_cast<const uint16_t*>(&sD[p + q][0])[lane];
+            float dv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dv[q] = __uint_as_float((uint32_t)draw[q] << 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx) {
+                        const float* xv = &sX[r][2 * (p + q) + sx][0];     // the same address in every lane: a broadcast read
+#pragma unroll
+                        for (int c = 0; c < CR; ++c) acc[r * 3 + sx][c] = fmaf(dv[q], xv[c], acc[r * 3 + sx][c]);
+                    }
+        }
+    }
+    // block total in fixed wave order -> slab [9][8][64] (rows c >= Cr are never read by the reducer)
+    __syncthreads();                                    // (sRed aliases the staging buffers)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < CR; ++c) sRed[wave][t * CR + c][lane] = acc[t][c];
+    __syncthreads();
+    float* slab = ws + (size_t)blockIdx.x * 9 * 8 * 64;
+    for (int i = tid; i < 9 * CR * 64; i += 256) {
+        const int row = i >> 6, k = i & 63;
+        const float v = ((sRed[0][row][k] + sRed[1][row][k]) + sRed[2][row][k]) + sRed[3][row][k];
+        slab[((row / CR) * 8 + (row % CR)) * 64 + k] = v;
+    }
+}
+
+// Reducer for MANY small slabs (D.h0: 512 slabs of a 27 x 64 result): wgrad_reduce_kernel gives every output its own thread, which
+// then walks all slabs -- 432 threads and 64 dependent rounds of loads here.  This one puts a WAVE on each 16-byte output: lane l sums
+// slabs l, l + 64, ... (all loads in flight), then a fixed-order butterfly; blockIdx.y = network of a two-network launch.
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* ws, float* dw, float* dw2, int taps, int C, int K, int Cr, int Kr, int splits, int accumulate) {
+    const int K4 = K / 4, lane = threadIdx.x & 63;
+    const int total = taps * Cr * K4;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= total) return;
+    const int net = blockIdx.y;
+    float* const out = net ? dw2 : dw;
+    const size_t slab = (size_t)taps * C * K;
+    const int k4 = i % K4, t = i / K4, c = t % Cr, tap = t / Cr;
+    const float* src = ws + (size_t)net * splits * slab + ((size_t)tap * C + c) * K + k4 * 4;
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int sp = lane; sp < splits; sp += 64) v += *reinterpret_cast<const f32x4*>(src + (size_t)sp * slab);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], off);
+    if (lane == 0) {
+        float* o = out + ((size_t)tap * Cr + c) * Kr + k4 * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (k4 * 4 + e < Kr) o[e] = accumulate ? o[e] + v[e] : v[e];
+    }
+}
+
+#define S2W_BLOCKS 512                                  // persistent blocks = slabs (1024 / 2048 measured 7 / 22 % slower)
+static bool s2n_wgrad_ok(const sgg_conv_desc* d) {
+    return use_glds() && d->dtype == SGG_BF16 && d->pad_mode == SGG_PAD_ZERO && d->R == 3 && d->S == 3 && d->stride == 2 && d->C == 8 && d->K == 64 &&
+           d->pad_t == 0 && d->pad_l == 0 && d->H == 2 * d->Ho && d->W == 2 * d->Wo;
+}
+static int s2n_wgrad_blocks(const sgg_conv_desc* d) {
+    const int units = d->N * d->Ho * ((d->Wo + S2W_SEG - 1) / S2W_SEG);
+    const int upb = (units + S2W_BLOCKS - 1) / S2W_BLOCKS;
+    return (units + upb - 1) / upb;
+}
+static int launch_s2n_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, float* ws, int Cr, hipStream_t s) {
+    const int units = d->N * d->Ho * ((d->Wo + S2W_SEG - 1) / S2W_SEG);
+    const int upb = (units + S2W_BLOCKS - 1) / S2W_BLOCKS, blocks = (units + upb - 1) / upb;
+    if (Cr > 4) return SGG_EUNSUPPORTED;                  // (run_wgrad sends wider inputs to the generic kernel)
+    // four channels per pixel although D.h0 has three (the fourth is the tensor's zero padding): 36 sums = 18 register PAIRS
+    // for v_pk_fma_f32 and one ds_read_b128 per tap; with 27 sums hipcc spent 90 v_mov per four pixels lining operands up
+    hipLaunchKernelGGL(conv3x3s2_narrow_wgrad_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, (const char*)x, (const char*)dy, ws,
+                       d->N, d->H, d->W, d->Ho, d->Wo, units, upb);
+    return sgg_check_launch();
+}
+
 static bool n7_fwd_ok(const sgg_conv_desc* d) {
     return sgg_config().n7 && d->dtype == SGG_BF16 && d->R == 7 && d->S == 7 && d->stride == 1 && d->C == 64 && d->K == 8 &&
            d->Ho == d->H && d->Wo == d->W && d->pad_t == 3 && d->pad_l == 3 && d->H >= 8 && d->W >= 8;
@@ -3918,6 +4081,7 @@ static bool wgrad_use_v2(const sgg_conv_desc* d) {
 static int wgrad_splits(const sgg_conv_desc* d) {
     int64_t P = (int64_t)d->N * d->Ho * d->Wo;
     if (halo_wgrad_ok(d)) return halo_wgrad_blocks(d);               // one slab per persistent block
+    if (s2n_wgrad_ok(d)) return s2n_wgrad_blocks(d);
     if (w9_ok(d)) return w9_splits(d);
     if (w9s_ok(d)) return w9s_splits(d);
     if (wgrad_use_v2(d)) {                                         // one 8-wave block per CU: ~256 blocks in all
@@ -4036,15 +4200,17 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
         }
     }
     int splits = wgrad_splits(d);
+    const bool s2n = sizeof(T) == 2 && s2n_wgrad_ok(d) && Cr <= 4;   // D.h0: the vector-ALU kernel, one slab per block
     a.pix_per_split = (int)align_up((size_t)((a.P + splits - 1) / splits), 64);
-    splits = (a.P + a.pix_per_split - 1) / a.pix_per_split;
+    if (!s2n) splits = (a.P + a.pix_per_split - 1) / a.pix_per_split;
     a.dHW = make_fastdiv((uint32_t)(d->Ho * d->Wo)); a.dW = make_fastdiv((uint32_t)d->Wo);
     size_t need = (size_t)splits * d->R * d->S * d->C * d->K * sizeof(float);
     if (ws_bytes < need * nets || !ws) return SGG_EWORKSPACE;
     int rc = SGG_OK;
     for (int net = 0; net < nets && rc == SGG_OK; ++net) {
     if (net) { a.x = (const char*)xb; a.dy = (const char*)dyb; a.ws = (float*)((char*)ws + need); }
-    if (wgrad_use_v2(d)) {
+    if (s2n) rc = launch_s2n_wgrad(d, a.x, a.dy, a.ws, Cr, s);
+    else if (wgrad_use_v2(d)) {
         constexpr size_t lds = 2 * 2 * (size_t)(sizeof(T) == 2 ? 64 : 32) * 256 * sizeof(T);
         SGG_LDS_ATTR((conv_wgrad_glds_kernel<T, false>), lds);
         SGG_LDS_ATTR((conv_wgrad_glds_kernel<T, true>), lds);
@@ -4059,6 +4225,12 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
     else rc = launch_wgrad_cfg<T, 128, 16, 4>(a, splits, s);
     }
     if (rc) return rc;
+    if (s2n) {
+        const int outs = d->R * d->S * Cr * (d->K / 4);
+        hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)((outs + 3) / 4), (unsigned)nets), dim3(256), 0, s, (const float*)ws, dw, dwb,
+                           d->R * d->S, d->C, d->K, Cr, Kr, splits, accumulate);
+        return sgg_check_launch();
+    }
     int64_t total = (int64_t)d->R * d->S * Cr * (d->K / 4) * nets;
     int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, dw, d->R * d->S, d->C, d->K, Cr, Kr, splits, accumulate, dwb);

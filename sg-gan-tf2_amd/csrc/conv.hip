@@ -3893,6 +3893,9 @@ struct W9SArgs {
     float* ws;           // [splits][9*C][K] f32 slabs
     int N, H, W, C, K, Ho, Wo, pad_t, pad_l;
     int tiles, tiles_per_split;
+    // two NETWORKS of one shape in one launch (as W9Args): splits [splits_per_net, 2 * splits_per_net) read xb / dyb
+    const char* xb; const char* dyb;
+    int splits_per_net;
 };
 
 __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_s2_kernel(W9SArgs a) {
@@ -3908,7 +3911,11 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_s2_kernel(W9SArgs a) {
     }
     const int split = lid / otiles, tl = lid - split * otiles;
     const int c0 = (tl / ktiles) * 64, n0 = (tl % ktiles) * 128;
-    const int t_beg = split * a.tiles_per_split;
+    const bool netb = split >= a.splits_per_net;          // second network's blocks (uniform per block)
+    const int nsplit = netb ? split - a.splits_per_net : split;
+    const char* const ax = netb ? a.xb : a.x;
+    const char* const ady = netb ? a.dyb : a.dy;
+    const int t_beg = nsplit * a.tiles_per_split;
     const int t_end = min(a.tiles, t_beg + a.tiles_per_split);
     const int tilesW = a.Wo / 64;
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
@@ -3925,7 +3932,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_s2_kernel(W9SArgs a) {
             const int d = wave * 2 + i;
             const int px = d * 4 + (lane >> 4), pos = lane & 15;
             const int key = wg2_key<bf16>(px) & 15;
-            const char* src = a.dy + ((((size_t)n * a.Ho + ho) * a.Wo + w0 + px) * a.K + n0) * 2 + ((pos ^ key) << 4);
+            const char* src = ady + ((((size_t)n * a.Ho + ho) * a.Wo + w0 + px) * a.K + n0) * 2 + ((pos ^ key) << 4);
             dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sD + d * 1024));
         }
         // x halo: 3 rows x 17 wave-instructions of 8 slots; wave w issues q = w, w+8, ...
@@ -3940,7 +3947,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_s2_kernel(W9SArgs a) {
             const int key = w9_xkey(k * W9S_PITCH + slot);
             const int hi = 2 * ho - a.pad_t + k, wi = 2 * w0 - a.pad_l + col;
             const bool ok = col <= 128 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            const char* src = ok ? a.x + ((((size_t)n * a.H + hi) * a.W + wi) * a.C + c0) * 2 + ((pos ^ key) << 4) : zero;
+            const char* src = ok ? ax + ((((size_t)n * a.H + hi) * a.W + wi) * a.C + c0) * 2 + ((pos ^ key) << 4) : zero;
             dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sX + (k * W9S_PITCH + sg * 8) * 128));
         }
     };
@@ -4178,16 +4185,25 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
             return rc9 ? rc9 : run_w9(d, W9Net{xb, dyb, nullptr, nullptr, dwb}, nullptr, Cr, Kr, accumulate, ws, ws_bytes, s);
         }
         if (w9s_ok(d)) {                                  // 3x3 s2: the same with a parity-de-interleaved halo
-            const int sp = w9s_splits(d);
-            size_t need9 = (size_t)sp * 9 * d->C * d->K * sizeof(float);
+            // Two networks (grouped call): ONE launch of the single call's grid in which each network gets half the blocks, i.e.
+            // half the slabs.  The split slabs are this kernel's main cost next to the operands -- 75 MB written and 75 MB read
+            // again per network at the generator's four stride-2 layers, for 67 MB of x and dy -- so the two-launch form of the
+            // grouped call paid them twice.  Half the slabs = another f32 summation order than the single call's: for these
+            // shapes the grouped result equals two single calls up to that order (1e-6 relative), not bit for bit.
+            int sp = w9s_splits(d);
+            const bool merged = xb && sp >= 2;
+            const int spn = merged ? sp / 2 : sp;                  // slabs per network
+            if (merged) sp = 2 * spn;
+            size_t need9 = (size_t)spn * 9 * d->C * d->K * sizeof(float);
             if (ws_bytes < need9 * nets || !ws) return SGG_EWORKSPACE;
             W9SArgs w;
             w.x = (const char*)x; w.dy = (const char*)dy; w.ws = (float*)ws;
+            w.xb = (const char*)(merged ? xb : x); w.dyb = (const char*)(merged ? dyb : dy); w.splits_per_net = merged ? spn : (1 << 30);
             w.N = d->N; w.H = d->H; w.W = d->W; w.C = d->C; w.K = d->K; w.Ho = d->Ho; w.Wo = d->Wo; w.pad_t = d->pad_t; w.pad_l = d->pad_l;
-            w.tiles = w9s_tiles(d); w.tiles_per_split = (w.tiles + sp - 1) / sp;
+            w.tiles = w9s_tiles(d); w.tiles_per_split = (w.tiles + spn - 1) / spn;
             SGG_LDS_ATTR(conv3x3_wgrad_halo_s2_kernel, 2 * W9S_STAGE);
             hipLaunchKernelGGL(conv3x3_wgrad_halo_s2_kernel, dim3((unsigned)(sp * (d->C / 64) * (d->K / 128))), dim3(512), 2 * W9S_STAGE, s, w);
-            if (xb) {
+            if (xb && !merged) {
                 w.x = (const char*)xb; w.dy = (const char*)dyb; w.ws = (float*)((char*)ws + need9);
                 hipLaunchKernelGGL(conv3x3_wgrad_halo_s2_kernel, dim3((unsigned)(sp * (d->C / 64) * (d->K / 128))), dim3(512), 2 * W9S_STAGE, s, w);
             }
@@ -4195,7 +4211,7 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
             if (rc9) return rc9;
             int64_t total9 = (int64_t)9 * Cr * (d->K / 4) * nets;
             int blocks9 = (int)((total9 + 255) / 256); if (blocks9 > 4096) blocks9 = 4096;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks9), dim3(256), 0, s, (const float*)ws, dw, 9, d->C, d->K, Cr, Kr, sp, accumulate, dwb);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks9), dim3(256), 0, s, (const float*)ws, dw, 9, d->C, d->K, Cr, Kr, spn, accumulate, dwb);
             return sgg_check_launch();
         }
     }

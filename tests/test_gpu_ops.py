@@ -545,6 +545,16 @@ def test_group2_launches_equal_two_single_calls(sg, cfg):
             K.bias_grad(dy[k * N:(k + 1) * N], ref, accumulate=accumulate)
             assert torch.equal(dbs[k], ref), ("bias grad", accumulate, k)
     # weight gradients: two main kernels + ONE slab reduce vs two full calls (also accumulating onto existing values)
+    # (the 3x3 stride-2 halo shapes give each network half the split slabs in one launch: same sums in another f32 order)
+    s2halo = stride == 2 and R == 3 and Ci % 64 == 0 and Co % 128 == 0 and dt == torch.bfloat16
+
+    def same(a, b, what):
+        if s2halo:
+            rel = float((a - b).norm() / b.norm())
+            assert rel < 1e-5, (what, rel)
+        else:
+            assert torch.equal(a, b), what
+
     for accumulate in (False, True):
         base = [r(R, R, Ci, Co), r(R, R, Ci, Co)]
         dws = [b.clone() for b in base]
@@ -552,7 +562,7 @@ def test_group2_launches_equal_two_single_calls(sg, cfg):
         for k in range(2):
             ref = base[k].clone()
             K.conv_wgrad(g, x[k * N:(k + 1) * N], dy[k * N:(k + 1) * N], ref, accumulate=accumulate)
-            assert torch.equal(dws[k], ref), ("wgrad", accumulate, k)
+            same(dws[k], ref, ("wgrad", accumulate, k))
     if stride == 2 and padding == "SAME" and H % 2 == 0 and W % 2 == 0:
         # the same weights as a Conv2DTranspose (module.py:254,258): x' = (2N, H/2, W/2, Co) -> (2N, H, W, Ci)
         gd = K.deconv_geom(N, H // 2, W // 2, Co, Ci, R, R, 2, dt)
@@ -570,7 +580,7 @@ def test_group2_launches_equal_two_single_calls(sg, cfg):
             sl = slice(k * N, (k + 1) * N)
             ref = torch.empty_like(dwt[k])
             K.deconv_wgrad(gd, xt[sl], x[sl], ref)
-            assert torch.equal(dwt[k], ref), ("deconv wgrad", k)
+            same(dwt[k], ref, ("deconv wgrad", k))
 
 
 @pytest.mark.gpu

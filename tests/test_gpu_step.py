@@ -543,10 +543,11 @@ def test_other_baseline_configs_run(sg, cfg):
 def test_paired_cycle_step_is_bit_identical_to_one_network_at_a_time(sg, cfg):
     """The lockstep sequencing of the cycle step (module._PairUnit: both generators / both discriminators on stacked batches,
     one launch per pair for the norms and the 3x3 halo GEMMs) against the one-network-at-a-time sequencing: same kernels per
-    image and the same accumulation order per network, so losses, images and every gradient are bitwise equal -- with ONE
-    exception: where both generators' 3x3 weight gradients share a launch (sgg_conv2d_bwd_weight_pair2) each network's dW is
-    the sum of 16 split slabs instead of 32, i.e. equal up to f32 summation order; those tensors (and what Adam makes of
-    them) are held to 1e-5 of their norm."""
+    image and the same accumulation order per network, so losses, images and every data gradient are bitwise equal -- with ONE
+    exception: where two networks' 3x3 weight gradients share a launch (sgg_conv2d_bwd_weight_pair2 for the generators' residual
+    blocks, the stride-2 halo shapes of sgg_conv2d_bwd_weight_group2 in both kinds of network) each network's dW is the sum of
+    half as many split slabs, i.e. equal up to f32 summation order; the parameter / slot / gradient buffers (and only those)
+    are held to 1e-5 of their norm."""
     dtype, width, blocks, N, H, W = cfg
     out, names = [], None
     for paired in (False, True):
@@ -561,8 +562,8 @@ def test_paired_cycle_step_is_bit_identical_to_one_network_at_a_time(sg, cfg):
     for name, a, b in zip(names, *out):
         if torch.equal(a, b):
             continue
-        # only generator parameter / slot / gradient buffers may differ, and only by summation order
-        assert name.startswith(("net0.", "net2.")), name
+        # only parameter / slot / gradient buffers may differ, and only by summation order
+        assert name.startswith("net"), name
         rel = float((a.double() - b.double()).norm() / b.double().norm())
         assert rel < 1e-5, (name, rel)
         inexact += 1

@@ -4179,10 +4179,13 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
     if constexpr (sizeof(T) == 2) {
         if (w9_ok(d)) {                                   // 3x3 s1: x halo resident, all taps per block
             if (!xb) return run_w9(d, W9Net{x, dy, nullptr, nullptr, dw}, nullptr, Cr, Kr, accumulate, ws, ws_bytes, s);
-            // (two networks in one launch of this kernel halve the slabs per network -- another summation order than the single
-            // call's; a grouped call promises the single call's bits, so here it is two launches)
+            // two networks (grouped call): one launch, half the blocks and half the split slabs per network -- as for the stride-2
+            // shapes below, the slabs are the kernel's main traffic (D.h3: 75 MB written + read per network); the result equals
+            // two single calls up to f32 summation order
+            const W9Net second{xb, dyb, nullptr, nullptr, dwb};
+            if (!(w9_splits(d) & 1)) return run_w9(d, W9Net{x, dy, nullptr, nullptr, dw}, &second, Cr, Kr, accumulate, ws, ws_bytes, s);
             int rc9 = run_w9(d, W9Net{x, dy, nullptr, nullptr, dw}, nullptr, Cr, Kr, accumulate, ws, ws_bytes, s);
-            return rc9 ? rc9 : run_w9(d, W9Net{xb, dyb, nullptr, nullptr, dwb}, nullptr, Cr, Kr, accumulate, ws, ws_bytes, s);
+            return rc9 ? rc9 : run_w9(d, second, nullptr, Cr, Kr, accumulate, ws, ws_bytes, s);
         }
         if (w9s_ok(d)) {                                  // 3x3 s2: the same with a parity-de-interleaved halo
             // Two networks (grouped call): ONE launch of the single call's grid in which each network gets half the blocks, i.e.

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of the normalise-on-load forward: where in the step the row transform runs (H3_NORM_AT variants) vs the separate apply pass
+# build first:  for n in 0 2 3; do python sg-gan-tf2_amd/build.py --variant na$n -DH3_NORM_AT=$n; done
 cd "$(dirname "$0")/.."
 OPS=fwd_pair,dgrad_pair,in_apply_pair,fwd_normload_pair
 for v in "" na0 na2 na3 ""; do

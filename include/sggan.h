@@ -188,7 +188,8 @@ int sgg_conv2d_bwd_data_group2(const sgg_conv_desc* d, const void* dy, const voi
                                void* dx, void* ws, size_t ws_bytes, void* stream);
 /* weight gradients of the two networks: their main kernels run back to back into two sets of split slabs, ONE reduce launch sums
  * both (each in the single call's order).  dw / dw2: the two networks' f32 gradients, layouts as sgg_conv2d_bwd_weight.
- * Exception -- the 3x3 all-taps halo shapes (stride 1 pad 1, or stride 2; 64 | C, 128 | K; also as Conv2DTranspose): ONE main launch in which each network
+ * Exception -- the 3x3 all-taps halo shapes (stride 1 pad 1, or stride 2; 64 | C, 128 | K; also as Conv2DTranspose) and the
+ * LDS-DMA kernel's shapes (K >= 256 and R*S*C >= 256): ONE main launch in which each network
  * gets half the blocks and half the split slabs (the slabs are that kernel's main memory traffic); the result then equals two
  * single calls up to f32 summation order (~1e-6 relative), not bit for bit. */
 int sgg_conv2d_bwd_weight_group2(const sgg_conv_desc* d, const void* x, const void* dy, float* dw, float* dw2, int C_real, int K_real,

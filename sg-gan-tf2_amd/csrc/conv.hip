@@ -81,6 +81,10 @@ struct WgradArgs {
     int N, H, W, C, K, R, S, stride, pad_t, pad_l, Ho, Wo, reflect;
     int P, pix_per_split;
     FastDiv dHW, dW;     // divide by Ho*Wo, Wo
+    // conv_wgrad_glds_kernel only: two NETWORKS of one shape in one launch -- splits [splits_per_net, 2 * splits_per_net) read
+    // xb / dyb over the same pixel ranges (each network gets half the blocks and half the slabs of a single call's grid)
+    const char* xb; const char* dyb;
+    int splits_per_net;
 };
 
 // Kernel-selection switches.  The shipped library always returns the defaults below and never reads the environment;
@@ -3206,7 +3210,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_glds_kernel(WgradArgs a) {
     }
     const int split = lid / tiles, tl = lid - split * tiles;
     const int m0 = (tl / tilesN) * BT, n0 = (tl % tilesN) * BT;
-    const int pbeg = split * a.pix_per_split;
+    const bool netb = split >= a.splits_per_net;          // second network's blocks (uniform per block)
+    if (netb) { a.x = a.xb; a.dy = a.dyb; }
+    const int pbeg = (netb ? split - a.splits_per_net : split) * a.pix_per_split;
     const int pend = min(a.P, pbeg + a.pix_per_split);
 
     // this thread stages LDS position `pos` of rows prow0 + RPS*i; it holds logical chunk pos ^ key(row)
@@ -4149,6 +4155,7 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S; a.stride = d->stride;
     a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.reflect = d->pad_mode == SGG_PAD_REFLECT;
     a.P = d->N * d->Ho * d->Wo;
+    a.xb = a.x; a.dyb = a.dy; a.splits_per_net = 1 << 30;
     if constexpr (sizeof(T) == 2) {                     // the two 7x7 layers with a 3-channel side
         if (use_glds() && (w7_head_ok(d) || w7_stem_ok(d))) {
             const bool stem = !w7_head_ok(d);
@@ -4220,20 +4227,25 @@ static int run_wgrad(const sgg_conv_desc* d, const void* x, const void* dy, floa
     }
     int splits = wgrad_splits(d);
     const bool s2n = sizeof(T) == 2 && s2n_wgrad_ok(d) && Cr <= 4;   // D.h0: the vector-ALU kernel, one slab per block
+    // grouped call of the LDS-DMA kernel: one launch, half the splits (= slabs: 8 MB each at D.h31) per network -- see the stride-2
+    // halo branch above; equal to two single calls up to f32 summation order
+    const bool merged = xb && !s2n && wgrad_use_v2(d) && splits >= 2;
+    if (merged) splits /= 2;
     a.pix_per_split = (int)align_up((size_t)((a.P + splits - 1) / splits), 64);
     if (!s2n) splits = (a.P + a.pix_per_split - 1) / a.pix_per_split;
     a.dHW = make_fastdiv((uint32_t)(d->Ho * d->Wo)); a.dW = make_fastdiv((uint32_t)d->Wo);
     size_t need = (size_t)splits * d->R * d->S * d->C * d->K * sizeof(float);
     if (ws_bytes < need * nets || !ws) return SGG_EWORKSPACE;
     int rc = SGG_OK;
-    for (int net = 0; net < nets && rc == SGG_OK; ++net) {
+    if (merged) { a.xb = (const char*)xb; a.dyb = (const char*)dyb; a.splits_per_net = splits; }
+    for (int net = 0; net < (merged ? 1 : nets) && rc == SGG_OK; ++net) {
     if (net) { a.x = (const char*)xb; a.dy = (const char*)dyb; a.ws = (float*)((char*)ws + need); }
     if (s2n) rc = launch_s2n_wgrad(d, a.x, a.dy, a.ws, Cr, s);
     else if (wgrad_use_v2(d)) {
         constexpr size_t lds = 2 * 2 * (size_t)(sizeof(T) == 2 ? 64 : 32) * 256 * sizeof(T);
         SGG_LDS_ATTR((conv_wgrad_glds_kernel<T, false>), lds);
         SGG_LDS_ATTR((conv_wgrad_glds_kernel<T, true>), lds);
-        dim3 grid((unsigned)(((d->R * d->S * d->C + 255) / 256) * ((d->K + 255) / 256) * splits));
+        dim3 grid((unsigned)(((d->R * d->S * d->C + 255) / 256) * ((d->K + 255) / 256) * splits * (merged ? 2 : 1)));
         const int bkp = sizeof(T) == 2 ? 64 : 32;                      // pixels per stage (BKP in the kernel)
         const int rf = sgg_config().wgrad_rowfast;
         if (rf && d->Wo % bkp == 0) hipLaunchKernelGGL((conv_wgrad_glds_kernel<T, true>), grid, dim3(512), lds, s, a);

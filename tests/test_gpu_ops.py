@@ -508,6 +508,7 @@ def test_timed_launch_hooks_put_events_on_the_kernel_dispatch(sg):
     ("D.h4-like: 34 output channels", 2, 5, 13, 512, 40, 3, 1, "SAME", torch.bfloat16),
     ("c2-like: stride-2 forward / stride-2 halo data gradient", 2, 64, 128, 64, 128, 3, 2, "SAME", torch.bfloat16),
     ("h0-like: 8 -> 64 channels, stride 2 (the narrow stride-2 data-gradient kernel)", 2, 32, 80, 8, 64, 3, 2, "SAME", torch.bfloat16),
+    ("h31-like: 4x4 stride-2 VALID, 256 -> 256 (the LDS-DMA weight-gradient kernel, two networks in one launch)", 2, 18, 34, 256, 256, 4, 2, "VALID", torch.bfloat16),
     ("h3-like: 256x256 tiles", 2, 32, 64, 256, 512, 3, 1, "SAME", torch.bfloat16),
     ("odd generic f32", 3, 9, 11, 16, 24, 3, 1, "SAME", torch.float32),
     ("3x3 stride-1 halo shape, zero padding", 2, 64, 128, 64, 64, 3, 1, "SAME", torch.bfloat16),
@@ -547,6 +548,7 @@ def test_group2_launches_equal_two_single_calls(sg, cfg):
     # weight gradients: two main kernels + ONE slab reduce vs two full calls (also accumulating onto existing values)
     # (the 3x3 halo weight-gradient kernels give each network half the split slabs in one launch: same sums in another f32 order)
     s2halo = stride in (1, 2) and R == 3 and Ci % 64 == 0 and Co % 128 == 0 and dt == torch.bfloat16   # (the all-taps halo kernels)
+    s2halo = s2halo or (Co >= 256 and R * R * Ci >= 256)                                              # (and the LDS-DMA kernel)
 
     def same(a, b, what):
         if s2halo:

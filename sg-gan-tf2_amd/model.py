@@ -414,10 +414,10 @@ class sggan(object):
         translation directions on the batch dimension -- [real_A; real_B] -> [fake_B; fake_A] -> [cyc_A; cyc_B] through
         (G_A->B, G_B->A) then (G_B->A, G_A->B); the fakes through (D_B, D_A), the reals through (D_A, D_B).  Convolutions still
         run per network; instance norms, activations and gradient joins run once per pair over twice the bytes.  Same kernels
-        per image, same accumulation order per network as _train_step_cycle: losses, images, data gradients and the
-        discriminators' parameter gradients are bit-identical to it; the generators' 3x3 weight gradients, where both networks
-        share a launch (sgg_conv2d_bwd_weight_pair2: 16 split slabs per network instead of 32), are equal up to f32 summation
-        order (held to 1e-5 of the tensor norm by the tests)."""
+        per image as _train_step_cycle: losses, images and data gradients are bit-identical to it; weight gradients of layers
+        whose two networks share a launch (sgg_conv2d_bwd_weight_pair2 and the all-taps / LDS-DMA shapes of
+        sgg_conv2d_bwd_weight_group2: half as many split slabs per network) are equal up to f32 summation order (held to 1e-5
+        of the tensor norm by the tests)."""
         Gab, Gba, Da, Db = self.generator, self.generator_BA, self.discriminator, self.discriminator_B
         if getattr(self, "_pairs", None) is None:
             self._pairs = (GeneratorPair(Gab, Gba), GeneratorPair(Gba, Gab), DiscriminatorPair(Db, Da), DiscriminatorPair(Da, Db))

@@ -30,7 +30,7 @@ def default_args(**over):
              segment_class=34, beta1=0.5, lr=0.0002, L1_lambda=10.0, Lg_lambda=5.0, use_resnet=True, use_pix2pix=False,
              use_lsgan=True, ratio_gan2seg=10, max_size=50, phase="train", dataset_dir="city",
              dtype="bf16", device="cuda", n_blocks=9, seed=19, graph=False, mixed=False, paired=True,
-             fuse_in_stats=True, fuse_in_bwd=False, g_buckets=3, keep_tapes=False, group2=True)
+             fuse_in_stats=True, fuse_in_bwd=False, g_buckets=3, keep_tapes=False, group2=True, d_quad=True)
     a.update(over)
     return SimpleNamespace(**a)
 
@@ -85,6 +85,7 @@ class sggan(object):
         self.use_pool = bool(g("use_pool", False))
         self.pair_wgrads = bool(g("pair_wgrads", True))   # cycle step: one weight-gradient launch per layer for both applications of a G
         self.batch_d_real_fake = bool(g("batch_d_real_fake", True))   # pool mode: D(real) and D(pooled fakes) as one 2N pass
+        self.d_quad = bool(g("d_quad", True))             # paired cycle step: reals and fakes through both discriminators as ONE stacked pass
         self.gen_loss_metric, self.disc_loss_metric, self._metric_n = 0.0, 0.0, 0
         # model.py:83-84 / 205-207: one Keras Adam per network (lr hard-coded 1e-3 on the live step; the cycle step
         # uses --lr).  d_optim / g_optim are the reference's attribute names; the cycle step adds the other two.
@@ -434,7 +435,15 @@ class sggan(object):
         m_ab = torch.cat([mA, mB])
         f1, t1 = Gp1.forward(x1)                              # [fake_B; fake_A]
         c2, t2 = Gp2.forward(f1)                              # [cyc_A; cyc_B]
-        Df, tDf = Dpf.forward(f1, m_ab)                       # [D_B(fake_B | mask_A); D_A(fake_A | mask_B)]
+        # Discriminators.  d_quad: reals AND fakes go through (D_B, D_A) as ONE stacked pass [real_B; fake_B | fake_A; real_A] --
+        # half the launches of the two passes it replaces (the discriminators' tails are launch-latency bound) and the weight
+        # gradients of both applications in one launch; the generators' loss backpropagates through the middle (fake) slice.
+        quad = self.d_quad and not self.keep_tapes
+        if quad:
+            Dq, tDq = Dpf.forward(torch.cat([rB, f1, rA]), torch.cat([mB, m_ab, mA]))
+            Df, tDf = Dq[n:3 * n], Dpf.slice_tape(tDq, n, 3 * n)
+        else:
+            Df, tDf = Dpf.forward(f1, m_ab)                   # [D_B(fake_B | mask_A); D_A(fake_A | mask_B)]
         wA, wB = K.seg_edge_weight(sA, C), K.seg_edge_weight(sB, C)
 
         crit = K.mse_const if self.use_lsgan else K.bce_logits
@@ -451,14 +460,23 @@ class sggan(object):
         K.gradloss(f1[lo], rA, wA, C, gl, d_f[lo], lam=self.Lg_lambda, accumulate_loss=True)
 
         # discriminator gradients (fakes are constants here): reals through (D_A, D_B), fakes through (D_B, D_A)
-        Dr, tDr = Dpr.forward(x1, m_ab)                       # [D_A(real_A | mask_A); D_B(real_B | mask_B)]
-        g_r, g_fk = e(Dr), e(Df)
-        crit(Dr[lo], 1.0, dl, g_r[lo], weight=0.5, accumulate_loss=False)
-        crit(Df[hi], 0.0, dl, g_fk[hi], weight=0.5, accumulate_loss=True)
-        crit(Dr[hi], 1.0, dl, g_r[hi], weight=0.5, accumulate_loss=True)
-        crit(Df[lo], 0.0, dl, g_fk[lo], weight=0.5, accumulate_loss=True)
-        Dpr.backward(tDr, g_r)
-        Dpf.backward(tDf, g_fk)
+        tDr = None
+        if quad:
+            g_q = e(Dq)                                       # [real_B; fake_B | fake_A; real_A], the loss terms in the same order as below
+            crit(Dq[3 * n:], 1.0, dl, g_q[3 * n:], weight=0.5, accumulate_loss=False)
+            crit(Dq[2 * n:3 * n], 0.0, dl, g_q[2 * n:3 * n], weight=0.5, accumulate_loss=True)
+            crit(Dq[:n], 1.0, dl, g_q[:n], weight=0.5, accumulate_loss=True)
+            crit(Dq[n:2 * n], 0.0, dl, g_q[n:2 * n], weight=0.5, accumulate_loss=True)
+            Dpf.backward(tDq, g_q)
+        else:
+            Dr, tDr = Dpr.forward(x1, m_ab)                   # [D_A(real_A | mask_A); D_B(real_B | mask_B)]
+            g_r, g_fk = e(Dr), e(Df)
+            crit(Dr[lo], 1.0, dl, g_r[lo], weight=0.5, accumulate_loss=False)
+            crit(Df[hi], 0.0, dl, g_fk[hi], weight=0.5, accumulate_loss=True)
+            crit(Dr[hi], 1.0, dl, g_r[hi], weight=0.5, accumulate_loss=True)
+            crit(Df[lo], 0.0, dl, g_fk[lo], weight=0.5, accumulate_loss=True)
+            Dpr.backward(tDr, g_r)
+            Dpf.backward(tDf, g_fk)
         hDa, hDb = self._allreduce(Da), self._allreduce(Db)
         # generator gradients: cycle terms first (they reach the other generator through the fakes).  Each generator is applied
         # twice, so the weight gradients of its 3x3 layers are paired: deferred in the first pass, launched with the second

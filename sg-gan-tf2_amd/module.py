@@ -776,6 +776,19 @@ class DiscriminatorPair:
             d = self.units[i].backward(tape[i], d, want_dx or i > 0, param_grads)
         return d
 
+    def slice_tape(self, tape, lo, hi):
+        """The forward records of images [lo, hi) of a stacked pass, as views: a backward pass through PART of the batch (the
+        cycle step sends reals and fakes through the discriminators as one pass, the generators' loss only needs the fakes).
+        The slice must hold as many images of the first network as of the second."""
+        k = (hi - lo) // 2
+        out = []
+        for pu, (g, x, xc, stats) in zip(self.units + [self.h4], tape[:-1]):
+            xs = x[lo:hi]
+            out.append((pu.ua.geom(xs[:k]), xs, xc[lo:hi], None if stats is None else stats[lo:hi]))
+        mask, h4_shape = tape[-1]
+        out.append((mask[lo:hi], (hi - lo,) + tuple(h4_shape[1:])))
+        return out
+
 
 # ----------------------------------------------------------------------------- autograd facade
 class _NetFn(torch.autograd.Function):

@@ -79,8 +79,10 @@ def test_train_loop_checkpoint_resume(sg, tmp_path):
 def test_cycle_step_with_image_pool(sg):
     """use_pool: D is trained on the pool's history; before the pool fills it is the current fakes (identical step)."""
     def run(use_pool):
+        # (d_quad off: the stacked real + fake discriminator pass of the pool-less step sums in another order -- equal to
+        # 1e-7, and this test wants the two modes' first steps identical)
         m = sg.sggan(sg.default_args(ngf=8, ndf=8, n_blocks=1, dtype="f32", cycle=True, use_pool=use_pool, max_size=2,
-                                     pool_rng=np.random.RandomState(0)))
+                                     pool_rng=np.random.RandomState(0), d_quad=False))
         g = torch.Generator().manual_seed(1)
         outs = []
         for _ in range(5):

@@ -551,7 +551,9 @@ def test_paired_cycle_step_is_bit_identical_to_one_network_at_a_time(sg, cfg):
     dtype, width, blocks, N, H, W = cfg
     out, names = [], None
     for paired in (False, True):
-        m = sg.sggan(sg.default_args(ngf=width, ndf=width, n_blocks=blocks, dtype=dtype, cycle=True, paired=paired))
+        # (d_quad off: the stacked real + fake discriminator pass has its own test below -- a 4N batch takes other split-K plans
+        # in the discriminators' small layers than two 2N batches, which is not what this test is about)
+        m = sg.sggan(sg.default_args(ngf=width, ndf=width, n_blocks=blocks, dtype=dtype, cycle=True, paired=paired, d_quad=False))
         m.real_A, m.seg_A, m.mask_A = _rand_inputs(N, H, W, m.discriminator, 61)
         m.real_B, m.seg_B, m.mask_B = _rand_inputs(N, H, W, m.discriminator, 62)
         m.train_step()
@@ -568,3 +570,36 @@ def test_paired_cycle_step_is_bit_identical_to_one_network_at_a_time(sg, cfg):
         assert rel < 1e-5, (name, rel)
         inexact += 1
     print("tensors equal up to f32 summation order only:", inexact)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [("f32", 16, 2, 2, 256, 256), ("f32", 64, 2, 1, 256, 512), ("bf16", 64, 2, 1, 256, 512)],
+                         ids=["f32_small", "f32_full_width", "bf16_full_width"])
+def test_stacked_real_and_fake_discriminator_pass_equals_two_passes(sg, cfg):
+    """d_quad (the default of the paired cycle step): reals and fakes go through (D_B, D_A) as ONE stacked pass
+    [real_B; fake_B | fake_A; real_A]; the discriminators' loss backpropagates through all of it, the generators' loss through the
+    middle slice (DiscriminatorPair.slice_tape).  Same mathematics as the two passes it replaces, in another f32 summation order:
+    a 4N batch takes other split-K plans in the discriminators' small layers (per image 4e-7 apart, tools/diag/dgrad_batch.py).
+    At full width with unscreened random inputs that is enough to move a few LeakyReLU pre-activations across zero (the kink
+    effect the f32 oracle tests screen their fixtures against: one flipped slope changes a gradient tensor by up to 1e-2), so
+    here the losses are held to 1e-6, the gradients to direction (1 - cos < 1e-4) and a loose norm bound; the accuracy of each
+    path against float64 is what the kink-aware oracle tests above hold to 2e-4 (they run with d_quad on, its default; the
+    paired-vs-one-network test covers the two-pass form).  In bf16 the last-bit differences also go through the roundings of
+    the discriminators' activations: losses to 2e-3, gradients by direction."""
+    dtype, width, blocks, N, H, W = cfg
+    out = []
+    for quad in (False, True):
+        m = sg.sggan(sg.default_args(ngf=width, ndf=width, n_blocks=blocks, dtype=dtype, cycle=True, paired=True, d_quad=quad))
+        m.real_A, m.seg_A, m.mask_A = _rand_inputs(N, H, W, m.discriminator, 61)
+        m.real_B, m.seg_B, m.mask_B = _rand_inputs(N, H, W, m.discriminator, 62)
+        m.train_step()
+        out.append([m._loss.clone()] + [n.P.grad.clone() for n in m.networks()])
+    (la, *ga), (lb, *gb) = out
+    lrel = float(((la - lb).abs() / lb.abs()).max())
+    rels = [float((a.double() - b.double()).norm() / b.double().norm()) for a, b in zip(ga, gb)]
+    coss = [float(torch.nn.functional.cosine_similarity(a.double().flatten(), b.double().flatten(), dim=0)) for a, b in zip(ga, gb)]
+    print("loss rel", lrel, "grad rel", rels, "1 - cos", [1 - c for c in coss])
+    if dtype == "f32":
+        assert lrel < 1e-6 and max(rels) < 2e-2 and min(coss) > 1 - 1e-4, (lrel, rels, coss)
+    else:
+        assert lrel < 2e-3 and min(coss) > 0.999, (lrel, coss)

@@ -85,7 +85,7 @@ class sggan(object):
         self.use_pool = bool(g("use_pool", False))
         self.pair_wgrads = bool(g("pair_wgrads", True))   # cycle step: one weight-gradient launch per layer for both applications of a G
         self.batch_d_real_fake = bool(g("batch_d_real_fake", True))   # pool mode: D(real) and D(pooled fakes) as one 2N pass
-        self.d_quad = bool(g("d_quad", True))             # paired cycle step: reals and fakes through both discriminators as ONE stacked pass
+        self.d_quad = bool(g("d_quad", True))             # reals and fakes through the discriminator(s) as ONE stacked pass (both step flavours)
         self.gen_loss_metric, self.disc_loss_metric, self._metric_n = 0.0, 0.0, 0
         # model.py:83-84 / 205-207: one Keras Adam per network (lr hard-coded 1e-3 on the live step; the cycle step
         # uses --lr).  d_optim / g_optim are the reference's attribute names; the cycle step adds the other two.
@@ -270,14 +270,23 @@ class sggan(object):
         D.P.zero_grad()
 
         fake, tG = G.forward(real)                                          # :175-179 (D2)
-        da_real, tDr = D.forward(seg, mask)                                 # :186
-        da_fake, tDf = D.forward(fake, mask)                                # :187 (= :188)
+        # :186-188.  d_quad: D sees [real; fake] as ONE stacked pass (half the launches; its tail layers are launch-latency bound);
+        # the generator's loss backpropagates through the fake slice of the same tape.  Per image the same arithmetic.
+        stack = self.d_quad and not self.keep_tapes
+        N = real.shape[0]
+        if stack:
+            da_both, tDq = D.forward(torch.cat([seg, fake]), torch.cat([mask, mask]))
+            da_real, da_fake = da_both[:N], da_both[N:]
+            tDr, tDf = None, D.slice_tape(tDq, N, 2 * N)
+        else:
+            da_real, tDr = D.forward(seg, mask)                             # :186
+            da_fake, tDf = D.forward(fake, mask)                            # :187 (= :188)
 
         # losses + their logit gradients, all on device (no host sync)
         gl, dl = self._loss[0:1], self._loss[1:2]
         d_fake_g = torch.empty_like(da_fake)
-        d_real_d = torch.empty_like(da_real)
-        d_fake_d = torch.empty_like(da_fake)
+        d_both_d = torch.empty((2 * N,) + tuple(da_real.shape[1:]), dtype=da_real.dtype, device=da_real.device)
+        d_real_d, d_fake_d = d_both_d[:N], d_both_d[N:]
         dfake_l1 = torch.empty_like(fake)
         K.bce_logits(da_fake, 1.0, gl, d_fake_g)                            # :153 gan_loss
         K.l1_loss(seg, fake, self.output_c_dim, gl, dfake_l1, weight=self.LAMBDA, accumulate=True)   # :155-156
@@ -285,8 +294,11 @@ class sggan(object):
         K.bce_logits(da_fake, 0.0, dl, d_fake_d, accumulate_loss=True)      # :163-164 (adds to disc_loss)
 
         # disc_tape.gradient(disc_loss, D vars)  (:197)
-        D.backward(tDr, d_real_d, want_dx=False, param_grads=True)
-        D.backward(tDf, d_fake_d, want_dx=False, param_grads=True)
+        if stack:
+            D.backward(tDq, d_both_d, want_dx=False, param_grads=True)
+        else:
+            D.backward(tDr, d_real_d, want_dx=False, param_grads=True)
+            D.backward(tDf, d_fake_d, want_dx=False, param_grads=True)
         hD = self._allreduce(D)
         # gen_tape.gradient(gen_loss, G vars)    (:196): through D's data path, then G
         dfake = D.backward(tDf, d_fake_g, want_dx=True, param_grads=False)

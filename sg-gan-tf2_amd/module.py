@@ -560,6 +560,17 @@ class Discriminator(_Net):
             d = self.units[i].backward(tape[i], d, want_dx or i > 0, param_grads, gbuf)
         return d
 
+    def slice_tape(self, tape, lo, hi):
+        """The forward records of images [lo, hi) of a pass, as views (a backward pass through part of the batch: the step sends
+        reals and fakes through D as one stacked pass, the generator's loss only needs the fakes)."""
+        out = []
+        for u, (g, x, xc, stats) in zip(self.conv_units(), tape[:-1]):
+            xs = x[lo:hi]
+            out.append((u.geom(xs), xs, xc[lo:hi], None if stats is None else stats[lo:hi]))
+        mask, h4_shape = tape[-1]
+        out.append((mask[lo:hi], (hi - lo,) + tuple(h4_shape[1:])))
+        return out
+
     def out_hw(self, H, W):
         """Spatial size of the h4 map for an HxW input (deviation D1: the mask grid to use above 128x128)."""
         def sz(n):

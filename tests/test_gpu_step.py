@@ -603,3 +603,19 @@ def test_stacked_real_and_fake_discriminator_pass_equals_two_passes(sg, cfg):
         assert lrel < 1e-6 and max(rels) < 2e-2 and min(coss) > 1 - 1e-4, (lrel, rels, coss)
     else:
         assert lrel < 2e-3 and min(coss) > 0.999, (lrel, coss)
+
+
+@pytest.mark.gpu
+def test_reference_step_stacked_discriminator_pass_equals_two_passes(sg):
+    """The same for the literal step (model.py:186-188): D([seg; fake]) as one stacked pass against D(seg), D(fake)."""
+    out = []
+    for quad in (False, True):
+        m = sg.sggan(sg.default_args(ngf=16, ndf=16, n_blocks=2, dtype="f32", d_quad=quad))
+        m.real_A, m.seg_A, m.mask_A = _rand_inputs(2, 256, 256, m.discriminator, 71)
+        m.train_step()
+        out.append([m._loss.clone()] + [n.P.grad.clone() for n in m.networks()])
+    (la, *ga), (lb, *gb) = out
+    lrel = float(((la - lb).abs() / lb.abs()).max())
+    rels = [float((a.double() - b.double()).norm() / b.double().norm()) for a, b in zip(ga, gb)]
+    print("loss rel", lrel, "grad rel", rels)
+    assert lrel < 1e-6 and max(rels) < 1e-4, (lrel, rels)

@@ -211,64 +211,59 @@ class EventProfiler:
         return out
 
 
-def cpu_baseline_cycle(H, W, seed, budget_s=40.0):
-    """PyTorch-CPU f32 restatement of the cycle-mode step at N=1 (kind "port"): 1 warm-up, then the median of up to 2 timed
-    steps -- as many as fit a 40 s wall-clock budget (one step of this shape takes ~15 s on the GPU node's host cores, the
-    warm-up ~18 s), so the driver's GPU lease is not spent on the CPU leg."""
-    from oracle import torch_restatement as T
-    from oracle import sggan_oracle as O
-    rng = np.random.default_rng(seed)
-    gs, ds = O.generator_param_shapes(), O.discriminator_param_shapes()
-    P = {n: O.init_params(sh, rng) for n, sh in (("Gab", gs), ("Gba", gs), ("Da", ds), ("Db", ds))}
-    img = lambda: rng.uniform(0, 1, (1, H, W, 3)).astype(np.float32)
-    mh, mw = O.disc_out_hw(H, W)
-    mk = lambda: np.stack([O.one_hot(rng.integers(0, 34, (mh, mw)), 34)]).astype(np.float32)
-    inputs = (img(), img(), img(), img(), mk(), mk())
-    S = T.CycleStep(P, torch.float32)
-    t0 = time.time()
-    S.step(*inputs)
-    warm = time.time() - t0
-    times = []
-    while len(times) < 2 and (not times or (time.time() - t0) + float(np.median(times)) < budget_s):
-        t1 = time.time()
-        S.step(*inputs)
-        times.append(time.time() - t1)
-    dt = float(np.median(times))
-    return {"value": 1.0 / dt, "unit": "images/sec", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"median of {len(times)} timed cycle-mode step(s) (2G+2D) of N=1 {W}x{H} f32 after 1 warm-up ({warm:.1f} s), as many "
-                      f"as fit a {budget_s:.0f} s budget (PyTorch-CPU restatement, oracle/torch_restatement.py CycleStep; not TF2); "
-                      f"step times {[round(t, 2) for t in times]} s; os.cpu_count()={os.cpu_count()}",
-            "gflops": step_gflop_per_image(H, W, "cycle") / dt}
+CPU_THREADS = 16        # the CPU leg's pinned thread count (see cpu_baseline): a one-GPU box's CPU share
 
 
-def cpu_baseline(H, W, seed, max_seconds=30.0):
-    """The PyTorch-CPU f32 restatement of the reference-mode step at N=1 (kind "port"), median of 3 steps after 1 warm-up
-    (fewer only if they do not fit the time budget)."""
+def cpu_baseline(H, W, seed, mode):
+    """The PyTorch-CPU f32 restatement (oracle/torch_restatement.py; kind "port" -- TensorFlow is not installed, so the reference's
+    own TF2-CPU path cannot be timed) on the host cores, N = 1, PINNED to CPU_THREADS threads: with PyTorch's default (128 threads
+    on this 256-CPU host) oneDNN's N = 1 convolutions oversubscribe and one cycle step took 18-32 s, moving 50 % between runs
+    (rounds 1-3); at 16 threads it takes ~2.4 s, at 32 ~3.5 s, at 64 ~6.6 s (tools/cpu_baseline_threads.py,
+    gpurun_out/r4_cpu_threads.txt).  Three samples, each the MEDIAN of its timed steps after one warm-up: `value` = the step the
+    headline times (cycle mode, or reference mode with --mode reference) at the headline's image size; beside it what SURVEY
+    8(d) specified -- the reference-mode step (model.py:169-200) at BASELINE configs[0]'s 256x256 and at 256x512."""
     from oracle import torch_restatement as T
     from oracle import sggan_oracle as O
-    rng = np.random.default_rng(seed)
-    PG = O.init_params(O.generator_param_shapes(), rng)
-    PD = O.init_params(O.discriminator_param_shapes(), rng)
-    real = rng.uniform(0, 1, (1, H, W, 3)).astype(np.float32)
-    seg = rng.uniform(0, 1, (1, H, W, 3)).astype(np.float32)
-    mh, mw = O.disc_out_hw(H, W)
-    mask = np.stack([O.one_hot(rng.integers(0, 34, (mh, mw)), 34)]).astype(np.float32)
-    S = T.RefStep(PG, PD, torch.float32)
-    t0 = time.time()
-    S.step(real, seg, mask)                       # warm-up (also bounds the sample)
-    warm = time.time() - t0
-    times = []
-    while len(times) < 3 and (time.time() - t0) + warm < max_seconds:
-        t1 = time.time()
-        S.step(real, seg, mask)
-        times.append(time.time() - t1)
-    if not times:
-        times = [warm]
-    dt = float(np.median(times))
-    return {"value": 1.0 / dt, "unit": "images/sec", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"{len(times)} reference-mode steps of N=1 {W}x{H} f32 (PyTorch-CPU restatement of model.py:169-200, "
-                      f"not TF2) after 1 warm-up, median; os.cpu_count()={os.cpu_count()}",
-            "gflops": step_gflop_per_image(H, W) / dt}
+    before = torch.get_num_threads()
+    threads = max(1, min(CPU_THREADS, len(os.sched_getaffinity(0))))
+    torch.set_num_threads(threads)
+    try:
+        gs, ds = O.generator_param_shapes(), O.discriminator_param_shapes()
+
+        def sample(h, w, cycle, n_timed):
+            rng = np.random.default_rng(seed)
+            img = lambda: rng.uniform(0, 1, (1, h, w, 3)).astype(np.float32)
+            mh, mw = O.disc_out_hw(h, w)
+            mk = lambda: np.stack([O.one_hot(rng.integers(0, 34, (mh, mw)), 34)]).astype(np.float32)
+            if cycle:
+                P = {n: O.init_params(sh, rng) for n, sh in (("Gab", gs), ("Gba", gs), ("Da", ds), ("Db", ds))}
+                S, inputs = T.CycleStep(P, torch.float32), (img(), img(), img(), img(), mk(), mk())
+            else:
+                S, inputs = T.RefStep(O.init_params(gs, rng), O.init_params(ds, rng), torch.float32), (img(), img(), mk())
+            t0 = time.time()
+            S.step(*inputs)
+            warm = time.time() - t0
+            times = []
+            for _ in range(n_timed):
+                t1 = time.time()
+                S.step(*inputs)
+                times.append(time.time() - t1)
+            dt = float(np.median(times))
+            return {"images_per_sec": 1.0 / dt, "median_step_s": dt, "step_times_s": [round(t, 3) for t in times], "warmup_s": round(warm, 3),
+                    "gflops": step_gflop_per_image(h, w, "cycle" if cycle else "reference") / dt,
+                    "what": f"{'cycle-mode step (2G+2D)' if cycle else 'reference-mode step (model.py:169-200, 1G+1D)'}, N=1 {w}x{h} f32"}
+
+        head = sample(H, W, mode == "cycle", 3 if mode == "cycle" else 5)
+        ref_small = sample(256, 256, False, 5)
+        ref_full = sample(H, W, False, 5) if mode == "cycle" else head
+    finally:
+        torch.set_num_threads(before)
+    return {"value": head["images_per_sec"], "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"median of {len(head['step_times_s'])} timed steps after 1 warm-up: {head['what']}; PyTorch-CPU restatement "
+                      f"(oracle/torch_restatement.py), not TF2; torch threads pinned to {threads} (os.cpu_count()={os.cpu_count()}, "
+                      f"affinity {len(os.sched_getaffinity(0))}); step times {head['step_times_s']} s",
+            "gflops": head["gflops"],
+            "reference_mode_256x256": ref_small, f"reference_mode_{W}x{H}": ref_full}
 
 
 class _StdoutToStderr:
@@ -463,7 +458,7 @@ def main():
                                                  "form per tensor byte (profiles/r02_in_traffic.json), scaled to the timed mix"}
         line["kernels"] = kt
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_cycle(a.height, a.width, 19) if a.mode == "cycle" else cpu_baseline(a.height, a.width, 19)
+            line["cpu_baseline"] = cpu_baseline(a.height, a.width, 19, a.mode)
         else:
             line["cpu_baseline"] = None
         if world == 1 and a.dtype != "f32" and not a.no_f32_leg:

@@ -12,6 +12,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define SGG_WAVE 64
 
@@ -49,6 +50,21 @@ template <> struct ET<bf16> {
         return c;
     }
 };
+
+// Exchange between the 16-lane rows of a wave (v_permlane16_swap_b32, new on gfx950): the ODD rows of `a` change places with the
+// EVEN rows of `b` -- afterwards a = {a row 0, b row 0, a row 2, b row 2}, b = {a row 1, b row 1, a row 3, b row 3}
+// (tools/probes/permlane16_swap.hip).  With a 16x16 MFMA accumulator D[channel 4 * row + e][pixel column] of two pixel
+// fragments in a / b this hands rows 0, 2 EIGHT consecutive channels of fragment a's pixel (a: 8 row' + 0..3, b: + 4..7) and rows
+// 1, 3 those of fragment b's: 16-byte stores instead of 8-byte ones.
+__device__ __forceinline__ void row_swap16(uint32_t& a, uint32_t& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+__device__ __forceinline__ void row_swap16(float& a, float& b) {
+    uint32_t x = __float_as_uint(a), y = __float_as_uint(b);
+    row_swap16(x, y);
+    a = __uint_as_float(x); b = __uint_as_float(y);
+}
 
 __device__ inline u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ inline void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
@@ -214,6 +230,20 @@ static inline void sgg_launch_timed(F kern, dim3 grid, dim3 block, unsigned lds,
     } else {
         hipLaunchKernelGGL(kern, grid, block, lds, s, args...);
     }
+}
+
+// compute units of the CURRENT device (persistent kernels size their grids by it); cached per device ordinal, 256 if the
+// query fails (MI355X)
+static inline int sgg_num_cus() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v <= 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cache[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
 }
 
 // kernel-selection switches (defaults = the shipped configuration); see sgg_config() in conv.hip

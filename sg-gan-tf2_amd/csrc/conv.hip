@@ -749,6 +749,18 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a_in) 
 #ifndef H3_ROT
 #define H3_ROT 1                                       // halo rows: 16-byte chunk c of row r sits at position (c + (r & 6)) & 7 (a rotation) instead of c ^ ((r >> 1) & 7)
 #endif
+#ifndef H3_PERSIST
+#define H3_PERSIST 1                                   // one block per CU walking consecutive tiles, the next tile's prologue issued under the epilogue (kernel header)
+#endif
+#ifndef H3_PRIMED_WAIT
+#define H3_PRIMED_WAIT 0                               // > 0: at a primed tile's head wait until <= this many vector-memory operations are outstanding (the epilogue's stores) instead of for all
+#endif
+#ifndef H3_PATCH_ROT
+#define H3_PATCH_ROT 1                                 // FOLD column patches laid out so that a patch lane reads the bank slot its halo read would have taken (below)
+#endif
+#ifndef H3_WIDE
+#define H3_WIDE 1                                      // epilogue: two pixel fragments' 8-byte (pixel, 4 channels) pieces exchanged between lane rows into 16-byte stores / addend loads
+#endif
 #ifndef H3_GJ
 #define H3_GJ 4                                        // pixel fragments per MFMA group of the main loop (x 4 weight fragments = 16 MFMAs)
 #endif
@@ -825,13 +837,34 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         const int q = nm >> 3, rr = nm & 7, xcd = b & 7;
         lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
     }
-    const int n0 = (lid % tilesN) * BN;
-    int mt = lid / tilesN;
-    const int tw = mt % tilesW; mt /= tilesW;
-    const int th = mt % tilesH;
-    const int img = mt / tilesH;
-    const int h0 = th * 2, w0 = tw * H3_TW;
-    const char* const wmat_n = PAIR && img >= a.nsplit ? a.wmat2 : a.wmat;
+    // PERSISTENT form (H3_PERSIST): the grid is one block per CU and a block walks `tpb` CONSECUTIVE tiles (rows of one image:
+    // neighbouring halos, one weight set); the next tile's prologue -- four halo rows, patch, weight tile 0: ~100 KB per block --
+    // is issued under the current tile's epilogue (between its addend loads and its stores), so only the first tile of a block
+    // pays for an exposed prologue and there is no second wave of block launches.  Same tiles, same arithmetic per tile.
+    struct Tile { int n0, img, h0, w0, tw, th; const char* wmat_n; bool hasL, hasR; };
+    auto tile_of = [&](int id) {
+        Tile c;
+        c.n0 = (id % tilesN) * BN;
+        int mt = id / tilesN;
+        c.tw = mt % tilesW; mt /= tilesW;
+        c.th = mt % tilesH;
+        c.img = mt / tilesH;
+        c.h0 = c.th * 2; c.w0 = c.tw * H3_TW;
+        c.wmat_n = PAIR && c.img >= a.nsplit ? a.wmat2 : a.wmat;
+        c.hasL = FOLD && c.tw == 0; c.hasR = FOLD && c.tw == tilesW - 1;
+        return c;
+    };
+    constexpr int ADDR = SRC == 0 ? H3_ADDR0 : (SRC == 1 ? H3_ADDR1 : H3_ADDR2);
+    constexpr bool PERSIST = H3_PERSIST && SRC != 2 && ADDR == 0 && STATS != 2;
+    const int total_tiles = tilesN * tilesW * tilesH * a.N;
+    const int tpb = PERSIST ? (total_tiles + (int)gridDim.x - 1) / (int)gridDim.x : 1;
+    bool primed = false;                               // this tile's prologue DMAs were issued under the previous tile's epilogue
+  for (int it = 0; it < tpb; ++it) {
+    const int tile_id = PERSIST ? lid * tpb + it : lid;
+    if (PERSIST && tile_id >= total_tiles) break;
+    const Tile cur = tile_of(tile_id);
+    const int n0 = cur.n0, tw = cur.tw, th = cur.th, img = cur.img, h0 = cur.h0, w0 = cur.w0;
+    const char* const wmat_n = cur.wmat_n;
     const bool dbg_clk = SGG_ABLATE_OF(a) == 9 && lid == 0 && tid == 0;
     const int abl = SGG_ABLATE_OF(a) >= 8 ? 0 : SGG_ABLATE_OF(a);    // 8, 9 = full kernel + clock stamps
     if (dbg_clk) { g_dbg_clk[0] = clock64(); g_dbg_clk[1] = wall_clock64(); }
@@ -855,7 +888,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     // arithmetic of form 0 runs in time the wave would wait anyway, and the denser issue of forms 1 / 2 only bunches the LDS
     // writes against the other waves' fragment reads.  Only the normalise-on-load variant uses form 1: it needs the registers.
     // (What did pay is the padding mode as a template parameter: 0.472 -> 0.495.)
-    constexpr int ADDR = SRC == 0 ? H3_ADDR0 : (SRC == 1 ? H3_ADDR1 : H3_ADDR2);
     static_assert(ADDR != 1 || SRC != 0, "the SGPR-base form has no zero padding");
     constexpr bool SADDR = ADDR == 1, BUFA = ADDR == 2;
     const char* vrows = FOLD ? a.fold + (size_t)a.N * a.H * 18 * SC * 2 : nullptr;   // [N][2][W][SC] after the patches
@@ -868,7 +900,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     // (Walking the channel chunks in a per-block rotated order -- so that the blocks of one XCD do not all want the
     // same weight tile at the same moment -- measured 1-2 % slower: first-touch L2 misses are not what the tiles wait for.)
     // (vw, nw): this wave acts as issuer vw of nw -- all 8 waves in the prologue, 4 issuer waves in the main loop
-    auto load_halo_row = [&](int k, int chunk, int vw, int nw) {
+    auto load_halo_row = [&](const Tile& c, int k, int chunk, int vw, int nw) {
+        const int h0 = c.h0, w0 = c.w0, img = c.img;          // (the tile being LOADED: the next one under an epilogue)
         int hi = h0 - 1 + k;
         bool rowok = true;
         if (mirror) hi = hi < 0 ? -hi : (hi >= a.H ? 2 * (a.H - 1) - hi : hi);
@@ -923,19 +956,37 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     };
 
     // ---- FOLD: column patch, row pe = (tile row * 2 + side) * 9 + tap (halo tap order), 5 DMAs by waves 0..4
-    const bool hasL = FOLD && tw == 0, hasR = FOLD && tw == tilesW - 1;
-    auto load_patch = [&](int chunk, int vw, int nw) {
+    const bool hasL = cur.hasL, hasR = cur.hasR;
+    auto load_patch = [&](const Tile& c, int chunk, int vw, int nw) {
         if (!FOLD) return;
+        const int h0 = c.h0, img = c.img;
+        const bool hasL = c.hasL, hasR = c.hasR;
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
             const int pw = vw + nw * qi;                                   // patch DMA 0..4
             if (pw >= H3_PATCH_ROWS / 8) break;
             const int pe = pw * 8 + hsub;
-            const int tap_h = pe % 9, side = (pe / 9) & 1, tr = pe / 18;
+            int tap_h, side, tr, schunk;
+            if (H3_PATCH_ROT && H3_ROT) {
+                // Patch row of (tile row tr, tap row r): 6 LDS rows, even ones for the entries whose halo read sits in an even halo
+                // row -- (L, sx 1), (R, sx 0), (R, sx 2) -- odd ones for (L, sx 0), (L, sx 2), (R, sx 1); chunk c at position
+                // (c + rot) & 7 with rot = the halo rotation of the row the lane would have read: L (1 + sx) & 6, R (14 + sx) & 6.
+                // The patch lane of a fragment read then hits exactly the bank slot (row parity, position) of the halo read it
+                // replaces, and the ds_read_b128 stays conflict-free (with the XOR-keyed patch rows 13 % of the data gradient's LDS
+                // cycles were conflict replays: at W = 128 every tile is both a left and a right edge).
+                const int grp = pe / 6, slot = pe - 6 * grp;
+                side = (0x34 >> slot) & 1;
+                const int sx = (0x681 >> (2 * slot)) & 3;
+                tr = grp / 3;
+                tap_h = (grp - 3 * tr) * 3 + sx;
+                schunk = (hpos - ((0x6c90 >> (3 * (side * 3 + sx))) & 7)) & 7;
+            } else {
+                tap_h = pe % 9; side = (pe / 9) & 1; tr = pe / 18;
+                schunk = hpos ^ ((pe >> 1) & 7);
+            }
             const bool ok = pe < 36 && (side ? hasR : hasL);
-            const int key = (pe >> 1) & 7;
             // a.fold first part: [N][H][2 sides][9 weight taps][SC]; halo tap t pairs with weight tap 8 - t
-            const char* src = ok ? a.fold + (((((size_t)img * a.H + h0 + tr) * 2 + side) * 9 + (8 - tap_h)) * SC + chunk * 64) * 2 + ((hpos ^ key) << 4)
+            const char* src = ok ? a.fold + (((((size_t)img * a.H + h0 + tr) * 2 + side) * 9 + (8 - tap_h)) * SC + chunk * 64) * 2 + (schunk << 4)
                                  : zero;
             dma16_to_lds(src, (__attribute__((address_space(3))) void*)(lPatch + ((chunk & 1) * H3_PATCH_ROWS + pw * 8) * 128));
         }
@@ -949,7 +1000,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     const int wsw = ((lane & 7) ^ ((lane >> 4) & 7)) << 4;
     const uint32_t wvoff0 = (uint32_t)(wl * wrow * 2 + wsw), wvoff1 = (uint32_t)(wl * wrow * 2 + (wsw ^ 64));
     if constexpr (BUFA) rsW = sgg_make_rsrc(wmat_n + (size_t)n0 * wrow * 2, (uint32_t)((DC - n0 < BN ? DC - n0 : BN) * wrow * 2));
-    auto load_w = [&](int stg, int chunk, int tap, int vw, int nw) {
+    auto load_w = [&](const Tile& c, int stg, int chunk, int tap, int vw, int nw) {
+        const int n0 = c.n0;
+        const char* const wmat_n = c.wmat_n;
         const char* const tbase = wmat_n + ((size_t)n0 * wrow + tap * SC + chunk * 64) * 2;
         const uint32_t wvoff = (vw & 1) ? wvoff1 : wvoff0;
         lds_char* sQ = lB + stg * (256 * 128);
@@ -1049,10 +1102,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     }
     // prologue: whole halo of chunk 0 + weight tile 0
 #pragma unroll
-    for (int k = 0; k < 4; ++k) load_halo_row(k, 0, wave, 8);
-    load_patch(0, wave, 8);
-    load_w(0, 0, MODE == MODE_FWD ? 0 : 8, wave, 8);
-    SGG_WAIT_VM0();
+    for (int k = 0; k < 4; ++k) if (!primed) load_halo_row(cur, k, 0, wave, 8);
+    if (!primed) { load_patch(cur, 0, wave, 8); load_w(cur, 0, 0, MODE == MODE_FWD ? 0 : 8, wave, 8); }
+    // (primed: the DMAs are older than the previous tile's stores, and vector-memory operations complete in issue order --
+    // waiting until at most the stores issued after them are outstanding leaves those in flight under this tile's first steps)
+    if (PERSIST && primed && H3_PRIMED_WAIT > 0) sgg_wait_vm<H3_PRIMED_WAIT>(); else SGG_WAIT_VM0();
     __builtin_amdgcn_s_barrier();
     if constexpr (NORM && !(H3_NORM_ABL & 4)) {
         // the tile's own rows (1, 2: stored to a.nout) by the waves that issue no DMAs in the main loop, the neighbours' rows by
@@ -1086,15 +1140,15 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             if ((wave >> 2) == H3_ISSUER_HALF) {           // the weight tile: 8 DMA instructions per issuer wave and tile
                 int ntap = tap + 1, nchk = chunk;
                 if (ntap == 9) { ntap = 0; ++nchk; }
-                if (t + 1 < ntiles) load_w((t + 1) & 1, nchk, MODE == MODE_FWD ? ntap : 8 - ntap, vw, 4);
+                if (t + 1 < ntiles) load_w(cur, (t + 1) & 1, nchk, MODE == MODE_FWD ? ntap : 8 - ntap, vw, 4);
             }
             if ((wave >> 2) == H3_HALO_HALF) {             // the halo rows (17 instructions each, ~1 row per tile on average)
-                if (tap == 0 && chunk > 0) load_halo_row(2, chunk, vw, 4);
+                if (tap == 0 && chunk > 0) load_halo_row(cur, 2, chunk, vw, 4);
                 if (tap == 3) {
-                    if (chunk > 0) load_halo_row(3, chunk, vw, 4);
-                    if (chunk + 1 < nchunk) { load_halo_row(0, chunk + 1, vw, 4); load_patch(chunk + 1, vw, 4); }
+                    if (chunk > 0) load_halo_row(cur, 3, chunk, vw, 4);
+                    if (chunk + 1 < nchunk) { load_halo_row(cur, 0, chunk + 1, vw, 4); load_patch(cur, chunk + 1, vw, 4); }
                 }
-                if (tap == 6 && chunk + 1 < nchunk) load_halo_row(1, chunk + 1, vw, 4);
+                if (tap == 6 && chunk + 1 < nchunk) load_halo_row(cur, 1, chunk + 1, vw, 4);
             }
         }
         H3_STAMP(1);
@@ -1107,16 +1161,19 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         const char* bP = sH + (hr * H3_PITCH + hc) * 128;
         const char* bQ = sB + (t & 1) * (256 * 128) + (wn * WN + frow) * 128;
         // FOLD: the lanes holding pixel column 1 (fragment 0) / W-2 (fragment MI-1) read their patch row instead
-        const int peL = (wm * 2 + 0) * 9 + tap, peR = (wm * 2 + 1) * 9 + tap;
+        constexpr bool PROT = H3_PATCH_ROT && H3_ROT;
+        // PROT: row (wm * 3 + r) * 6 + slot, slot L = {1, 0, 3}[sx], R = {2, 5, 4}[sx]; rotation L = {0, 2, 2}[sx], R = {6, 6, 0}[sx] (load_patch)
+        const int peL = PROT ? (wm * 3 + r) * 6 + ((0x31 >> (2 * sx)) & 3) : (wm * 2 + 0) * 9 + tap;
+        const int peR = PROT ? (wm * 3 + r) * 6 + 2 + ((0x2c >> (2 * sx)) & 3) : (wm * 2 + 1) * 9 + tap;
         const char* pL = sPatch + ((chunk & 1) * H3_PATCH_ROWS + peL) * 128;
         const char* pR = sPatch + ((chunk & 1) * H3_PATCH_ROWS + peR) * 128;
-        const int keyL = (peL >> 1) & 7, keyR = (peR >> 1) & 7;
+        const int keyL = PROT ? ((0x90 >> (3 * sx)) & 7) : (peL >> 1) & 7, keyR = PROT ? ((0x36 >> (3 * sx)) & 7) : (peR >> 1) & 7;
         const bool isL = hasL && frow == 1, isR = hasR && frow == 14;
         auto ldP = [&](int j, int kk) -> u32x4 {
             const char* p = bP + j * 16 * BKB + ((H3_ROT ? ((fq + 4 * kk + fswP) & 7) : ((fq + 4 * kk) ^ fswP)) << 4);
             if (FOLD) {
-                if (j == 0 && isL) p = pL + (((fq + 4 * kk) ^ keyL) << 4);
-                if (j == MI - 1 && isR) p = pR + (((fq + 4 * kk) ^ keyR) << 4);
+                if (j == 0 && isL) p = pL + ((PROT ? ((fq + 4 * kk + keyL) & 7) : ((fq + 4 * kk) ^ keyL)) << 4);
+                if (j == MI - 1 && isR) p = pR + ((PROT ? ((fq + 4 * kk + keyR) & 7) : ((fq + 4 * kk) ^ keyR)) << 4);
             }
             return ld16(p);
         };
@@ -1182,6 +1239,21 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
 
     if (dbg_clk) { g_dbg_clk[2] = clock64(); g_dbg_clk[3] = wall_clock64(); }
     if (abl == 6) return;
+    // the next tile's prologue (PERSIST): every wave past the main loop's last barrier, so the halo, patch buffer 0 and weight
+    // stage 0 are free.  Called once per tile from the epilogue, behind its loads and in front of its stores.
+    auto prime_next = [&]() {
+        primed = false;
+        if constexpr (PERSIST) {
+            if (it + 1 < tpb && tile_id + 1 < total_tiles && abl == 0) {
+                const Tile nx = tile_of(tile_id + 1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) load_halo_row(nx, k, 0, wave, 8);
+                load_patch(nx, 0, wave, 8);
+                load_w(nx, 0, 0, MODE == MODE_FWD ? 0 : 8, wave, 8);
+                primed = true;
+            }
+        }
+    };
     // Epilogue, one 16-channel group at a time.  STATS 1 (forward): per-channel (sum, sumsq) of the STORED output for the
     // instance norm that follows the conv.  STATS 2 (data gradient): the first pass of the instance-norm BACKWARD that
     // consumes this gradient, (sum g, sum g*xhat) with g = dx * act'(gamma*xhat + beta) and xhat from that norm's input
@@ -1206,7 +1278,65 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         // are dead here.  (With the tests inside the unrolled loops every load was followed by s_waitcnt vmcnt(0): 32 dependent
         // round trips at the tail of a grid that has nothing else to overlap them with.)
         const bool plain = a.act == SGG_ACT_NONE && !(MODE != MODE_FWD && (a.dst_f32 || a.addend_f32));
-        if (plain) {
+        if (plain && H3_WIDE) {
+            // A lane holds 4 consecutive channels of one pixel per fragment: 8-byte stores, 32 per lane, and the tail of a grid
+            // whose blocks all store at once is store-ISSUE bound.  Fragments 2 jp and 2 jp + 1 trade their halves between lane
+            // rows (row_swap16) so that every lane owns 8 consecutive channels of ONE pixel -- lanes of rows 0 / 2 a pixel of the
+            // even fragment, rows 1 / 3 one of the odd fragment: 16 stores of 16 bytes (and 16 addend loads instead of 32).  Same
+            // values, same roundings, same statistics (taken before the exchange); pixel-major order as before.
+            auto run = [&](auto has_add) {
+                constexpr bool ADD = decltype(has_add)::value;
+                const int jo = fq & 1, cb = (fq >> 1) * 8;
+                const size_t e0 = (prow + jo * 16 + frow) * DC + n0 + wn * WN + cb;   // element (fragment pair 0, group 0) of this lane
+                const size_t ej2 = (size_t)32 * DC;
+                u32x4 adv[MI / 2][NI];
+                if constexpr (ADD) {
+#pragma unroll
+                    for (int jp = 0; jp < MI / 2; ++jp)
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) {
+                            adv[jp][i] = zero16();
+                            if (n0 + wn * WN + i * 16 + cb < DC) adv[jp][i] = ld16(reinterpret_cast<const bf16*>(a.addend) + e0 + jp * ej2 + i * 16);
+                        }
+                }
+                prime_next();
+#pragma unroll
+                for (int jp = 0; jp < MI / 2; ++jp) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        float v0[4], v1[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] = acc[i][2 * jp][e] + bv[i][e]; v1[e] = acc[i][2 * jp + 1][e] + bv[i][e]; }
+                        u32x4 pk;
+                        if constexpr (ADD) {
+                            float ad[8], o[8];
+                            ET<bf16>::unpack(adv[jp][i], ad);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { row_swap16(v0[e], v1[e]); o[e] = v0[e] + ad[e]; o[4 + e] = v1[e] + ad[4 + e]; }
+                            pk = ET<bf16>::pack(o);
+                        } else {
+                            const bf16x4 p0 = {(bf16)v0[0], (bf16)v0[1], (bf16)v0[2], (bf16)v0[3]}, p1 = {(bf16)v1[0], (bf16)v1[1], (bf16)v1[2], (bf16)v1[3]};
+                            if (STATS == 1) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {           // (fragment order as in the 8-byte form: 2 jp, then 2 jp + 1)
+                                    const float r0 = (float)p0[e]; s1[i][e] += r0; s2[i][e] += r0 * r0;
+                                }
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float r1 = (float)p1[e]; s1[i][e] += r1; s2[i][e] += r1 * r1;
+                                }
+                            }
+                            const u32x2 q0 = __builtin_bit_cast(u32x2, p0), q1 = __builtin_bit_cast(u32x2, p1);
+                            uint32_t a0 = q0[0], a1 = q0[1], b0 = q1[0], b1 = q1[1];
+                            row_swap16(a0, b0); row_swap16(a1, b1);
+                            pk = (u32x4){a0, a1, b0, b1};
+                        }
+                        if (n0 + wn * WN + i * 16 + cb < DC) st16(reinterpret_cast<bf16*>(a.dst) + e0 + jp * ej2 + i * 16, pk);
+                    }
+                }
+            };
+            if (MODE != MODE_FWD && a.addend) run(std::true_type{}); else run(std::false_type{});
+        } else if (plain) {
             auto run = [&](auto has_add) {
                 constexpr bool ADD = decltype(has_add)::value;
                 const size_t e0 = (prow + frow) * DC + n0 + wn * WN + fq * 4;      // element (pixel j = 0, group i = 0) of this lane
@@ -1222,6 +1352,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
                             if (dc < DC) adv[j][i] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(a.addend) + e0 + j * ej + i * 16);
                         }
                 }
+                prime_next();
 #pragma unroll
                 for (int j = 0; j < MI; ++j) {
 #pragma unroll
@@ -1246,6 +1377,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             };
             if (MODE != MODE_FWD && a.addend) run(std::true_type{}); else run(std::false_type{});
         } else {
+            prime_next();
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
                 const size_t dpix = prow + j * 16 + frow;
@@ -1304,7 +1436,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
                 }
             }
         }
-        return;
     }
     // STATS 2 (data gradient; no bias, no activation -- run_gemm checks).  The norm's input tile (2 rows x 128 pixels x 256
     // channels = 128 KB) is first DMA'd into LDS -- the halo and the weight stages are free now -- with coalesced 16-byte
@@ -1411,6 +1542,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             }
         }
     }
+  }   // tile loop
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1647,7 +1779,13 @@ static int launch_halo3(const ConvArgs& a, hipStream_t s) {
     constexpr int lds = (FOLD ? H3_LDS_FOLD : H3_LDS) + (SRC == 2 ? H3_NORM_MAXC * 8 : 0);
     SGG_LDS_ATTR(kern, lds);
     const int DC = MODE == MODE_FWD ? a.K : a.C;
-    const int64_t blocks = (int64_t)a.N * (a.H / 2) * (a.W / H3_TW) * ((DC + 255) / 256);
+    int64_t blocks = (int64_t)a.N * (a.H / 2) * (a.W / H3_TW) * ((DC + 255) / 256);
+    // persistent form: one block per CU (one fits: >= 134 KB of LDS), each walking ceil(tiles / blocks) consecutive tiles
+    constexpr int ADDR = SRC == 0 ? H3_ADDR0 : (SRC == 1 ? H3_ADDR1 : H3_ADDR2);
+    if (H3_PERSIST && SRC != 2 && ADDR == 0 && STATS != 2 && SGG_ABLATE_OF(a) == 0) {
+        const int64_t cus = sgg_num_cus();
+        if (blocks > cus) { const int64_t tpb = (blocks + cus - 1) / cus; blocks = (blocks + tpb - 1) / tpb; }
+    }
     sgg_launch_timed(kern, dim3((unsigned)blocks), dim3(512), (unsigned)lds, s, a);
     return sgg_check_launch();
 }
@@ -1984,7 +2122,8 @@ __global__ __launch_bounds__(512) void conv7_narrow_out_kernel(N7Args a) {
 // MirrorPadGrad for REFLECT pad 3 (tf.pad backward in front of the stem, module.py:230): dxp is the data gradient on the
 // PADDED grid (N, H+6, W+6, 4) f32; every image pixel sums its (up to 2 x 2) mirror pre-images in fixed order and is
 // rounded to bf16 once.
-__global__ __launch_bounds__(256) void pad3_fold_kernel(const f32x4* dxp, char* dx, int N, int H, int W) {
+// addend (nullable, (N,H,W,8) bf16 like dx): added before the one rounding (a gradient join folded into the store).
+__global__ __launch_bounds__(256) void pad3_fold_kernel(const f32x4* dxp, const char* addend, char* dx, int N, int H, int W) {
     const int64_t total = (int64_t)N * H * W;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int w = (int)(i % W);
@@ -1998,6 +2137,10 @@ __global__ __launch_bounds__(256) void pad3_fold_kernel(const f32x4* dxp, char* 
                 const f32x4 d = dxp[((size_t)n * (H + 6) + jh[ih]) * (W + 6) + jw[iw]];
                 v0 += d[0]; v1 += d[1]; v2 += d[2];
             }
+        if (addend) {
+            const bf16x4 ad = *reinterpret_cast<const bf16x4*>(addend + (size_t)i * 16);
+            v0 += (float)ad[0]; v1 += (float)ad[1]; v2 += (float)ad[2];
+        }
         u32x4 pk = zero16();
         const bf16 b0 = (bf16)v0, b1 = (bf16)v1, b2 = (bf16)v2;
         pk[0] = (uint32_t)__builtin_bit_cast(uint16_t, b0) | ((uint32_t)__builtin_bit_cast(uint16_t, b1) << 16);
@@ -2367,9 +2510,11 @@ struct S2NArgs {
     const char* w;       // w_dgrad [8][9*64] bf16 (rows = dx channels)
     const char* w2;
     char* dx;            // (N,H,W,8) bf16
+    const char* addend;  // nullable, like dx: added to the result before its one rounding (a gradient join folded into the store)
     int N, nsplit, H, W, Ho, Wo, items, items_per_wave;
 };
 
+template <bool ADD>
 __global__ __launch_bounds__(256) void conv3x3s2_narrow_dgrad_kernel(S2NArgs a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int frow = lane & 15, fq = lane >> 4;
@@ -2424,11 +2569,23 @@ __global__ __launch_bounds__(256) void conv3x3s2_narrow_dgrad_kernel(S2NArgs a) 
         mac(1, 1, 1, 1, 1, 1);
         // D[channel = 4 fq + e][pixel = frow]: lanes fq < 2 hold the 8 channels of column pair j
         if (fq < 2 && j < a.Wo) {
+            bf16x4 ad[2][2];
+            if (ADD) {
+#pragma unroll
+                for (int py = 0; py < 2; ++py)
+#pragma unroll
+                    for (int px = 0; px < 2; ++px)
+                        ad[py][px] = *reinterpret_cast<const bf16x4*>(a.addend + ((((size_t)n * a.H + 2 * m + py) * a.W + 2 * j + px) * 8 + fq * 4) * 2);
+            }
 #pragma unroll
             for (int py = 0; py < 2; ++py)
 #pragma unroll
                 for (int px = 0; px < 2; ++px) {
-                    const f32x4 v = acc[py][px];
+                    f32x4 v = acc[py][px];
+                    if (ADD) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)ad[py][px][e];
+                    }
                     const bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
                     *reinterpret_cast<bf16x4*>(a.dx + ((((size_t)n * a.H + 2 * m + py) * a.W + 2 * j + px) * 8 + fq * 4) * 2) = pk;
                 }
@@ -2440,15 +2597,16 @@ static bool s2n_dgrad_ok(const sgg_conv_desc* d) {
     return use_glds() && d->dtype == SGG_BF16 && d->pad_mode == SGG_PAD_ZERO && d->R == 3 && d->S == 3 && d->stride == 2 && d->C == 8 && d->K == 64 &&
            d->pad_t == 0 && d->pad_l == 0 && d->H == 2 * d->Ho && d->W == 2 * d->Wo;
 }
-static int launch_s2n_dgrad(const sgg_conv_desc* d, const void* dy, const void* w, const void* w2, int nsplit, void* dx, hipStream_t s) {
+static int launch_s2n_dgrad(const sgg_conv_desc* d, const void* dy, const void* w, const void* w2, int nsplit, const void* addend, void* dx, hipStream_t s) {
     S2NArgs q;
-    q.dy = (const char*)dy; q.w = (const char*)w; q.w2 = (const char*)(w2 ? w2 : w); q.dx = (char*)dx;
+    q.dy = (const char*)dy; q.w = (const char*)w; q.w2 = (const char*)(w2 ? w2 : w); q.dx = (char*)dx; q.addend = (const char*)addend;
     q.N = d->N; q.nsplit = w2 ? nsplit : d->N; q.H = d->H; q.W = d->W; q.Ho = d->Ho; q.Wo = d->Wo;
     q.items = d->N * d->Ho * ((d->Wo + 15) / 16);
     const int waves = 256 * 16;                          // 16 waves per CU, each walking a contiguous run of items
     q.items_per_wave = (q.items + waves - 1) / waves;
     const int blocks = ((q.items + q.items_per_wave - 1) / q.items_per_wave + 3) / 4;
-    hipLaunchKernelGGL(conv3x3s2_narrow_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, q);
+    if (addend) hipLaunchKernelGGL(conv3x3s2_narrow_dgrad_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, q);
+    else hipLaunchKernelGGL(conv3x3s2_narrow_dgrad_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, q);
     return sgg_check_launch();
 }
 
@@ -4390,8 +4548,8 @@ static int conv2d_bwd_data_impl(const sgg_conv_desc* d, const void* dy, const vo
         // REFLECT: add the mirrored (MirrorPadGrad) terms of the border pixels with the small register-path launch
         return d->dtype == SGG_BF16 ? launch_gemm<bf16, MODE_BORDER>(a, (hipStream_t)stream) : launch_gemm<float, MODE_BORDER>(a, (hipStream_t)stream);
     }
-    if (!addend && !nb && s2n_dgrad_ok(d)) return launch_s2n_dgrad(d, dy, w, nullptr, 0, dx, (hipStream_t)stream);
-    if (!addend && !nb && use_glds() && n7_dgrad_ok(d)) {
+    if (!nb && s2n_dgrad_ok(d)) return launch_s2n_dgrad(d, dy, w, nullptr, 0, addend, dx, (hipStream_t)stream);
+    if (!nb && use_glds() && n7_dgrad_ok(d)) {            // (addend: joined in the fold pass, before its one rounding)
         // the stem: data gradient on the PADDED grid (a zero-padded "full" correlation of dy with the mirrored taps, f32),
         // then MirrorPadGrad as a fold of the 3-pixel frame onto the image -- one rounding, no separate border GEMM
         if (!ws || ws_bytes < n7_dgrad_ws(d)) return SGG_EWORKSPACE;
@@ -4403,7 +4561,7 @@ static int conv2d_bwd_data_impl(const sgg_conv_desc* d, const void* dy, const vo
         if (rc0) return rc0;
         const int64_t total = (int64_t)d->N * d->H * d->W;
         int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(pad3_fold_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)ws, (char*)dx, d->N, d->H, d->W);
+        hipLaunchKernelGGL(pad3_fold_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)ws, (const char*)addend, (char*)dx, d->N, d->H, d->W);
         return sgg_check_launch();
     }
     if (!addend && halo_dgrad_narrow_ok(d)) {
@@ -4544,12 +4702,12 @@ int sgg_conv2d_bwd_data_group2(const sgg_conv_desc* d, const void* dy, const voi
                                void* ws, size_t ws_bytes, void* stream) {
     if (!desc_ok(d) || !dy || !w || !w2 || !dx) return SGG_EINVAL;
     const size_t xin = tensor_bytes(d, false), yout = tensor_bytes(d, true);
-    if (!addend && s2n_dgrad_ok(d)) {                    // D.h0: one launch over the stacked batch, weights picked per image
+    if (s2n_dgrad_ok(d)) {                               // D.h0: one launch over the stacked batch, weights picked per image
         sgg_conv_desc d2 = *d;
         d2.N = 2 * d->N;
-        return launch_s2n_dgrad(&d2, dy, w, w2, d->N, dx, (hipStream_t)stream);
+        return launch_s2n_dgrad(&d2, dy, w, w2, d->N, addend, dx, (hipStream_t)stream);
     }
-    const bool special = !use_glds() || (!addend && (halo_narrow_in_ok(d, d->K, d->C) || n7_dgrad_ok(d) || halo_dgrad_narrow_ok(d))) || fold_bytes(d) > 0;
+    const bool special = !use_glds() || n7_dgrad_ok(d) || (!addend && (halo_narrow_in_ok(d, d->K, d->C) || halo_dgrad_narrow_ok(d))) || fold_bytes(d) > 0;
     if (special) {                                       // (REFLECT shapes of the 3x3 halo kernel: sgg_conv2d_bwd_data_pair)
         int rc = sgg_conv2d_bwd_data(d, dy, w, addend, dx, ws, ws_bytes, stream);
         return rc ? rc : sgg_conv2d_bwd_data(d, (const char*)dy + yout, w2, addend ? (const char*)addend + xin : nullptr, (char*)dx + xin, ws, ws_bytes, stream);

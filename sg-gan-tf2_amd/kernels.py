@@ -364,12 +364,15 @@ def _stacked(shape):
     return (2 * shape[0],) + tuple(shape[1:])
 
 
-def conv_fwd_group2(g: ConvGeom, x, w_fwd, bias, w_fwd2, bias2, act=A.ACT_NONE, leak=0.0):
+def conv_fwd_group2(g: ConvGeom, x, w_fwd, bias, w_fwd2, bias2, act=A.ACT_NONE, leak=0.0, out=None):
     assert tuple(x.shape) == _stacked(g.x_shape) and not g.is_deconv
-    y = torch.empty(_stacked(g.y_shape), dtype=x.dtype, device=x.device)
+    y = _out(out, _stacked(g.y_shape), x.dtype, x.device)
     ws = workspace(2 * g.ws_fwd, x.device) if g.ws_fwd else None
+    pr = _prof("conv2d_fwd_group2", g)
+    if pr: pr.start()
     A.check(A.lib().sgg_conv2d_fwd_group2(C.byref(g.desc), _p(x), _p(w_fwd), _p(bias), _p(w_fwd2), _p(bias2), _p(y), act, leak,
                                           _p(ws), 2 * g.ws_fwd, _s()), "conv2d_fwd_group2")
+    if pr: pr.stop()
     return y
 
 
@@ -378,8 +381,11 @@ def conv_dgrad_group2(g: ConvGeom, dy, w_dgrad, w_dgrad2, addend=None):
     assert addend is None or (tuple(addend.shape) == _stacked(g.x_shape) and addend.dtype == dy.dtype)
     dx = torch.empty(_stacked(g.x_shape), dtype=dy.dtype, device=dy.device)
     ws = workspace(2 * g.ws_dgrad, dy.device) if g.ws_dgrad else None
+    pr = _prof("conv2d_bwd_data_group2", g)
+    if pr: pr.start()
     A.check(A.lib().sgg_conv2d_bwd_data_group2(C.byref(g.desc), _p(dy), _p(w_dgrad), _p(w_dgrad2), _p(addend), _p(dx),
                                                _p(ws), 2 * g.ws_dgrad, _s()), "conv2d_bwd_data_group2")
+    if pr: pr.stop()
     return dx
 
 
@@ -388,16 +394,22 @@ def conv_wgrad_group2(g: ConvGeom, x, dy, dw, dw2, accumulate=False):
     assert tuple(x.shape) == _stacked(g.x_shape) and tuple(dy.shape) == _stacked(g.y_shape) and dw.shape == dw2.shape
     ws = workspace(2 * g.ws_wgrad, x.device)
     fn = A.lib().sgg_deconv2d_bwd_weight_group2 if g.is_deconv else A.lib().sgg_conv2d_bwd_weight_group2
+    pr = _prof("bwd_weight_group2", g)
+    if pr: pr.start()
     A.check(fn(C.byref(g.desc), _p(x), _p(dy), _p(dw), _p(dw2), dw.shape[2], dw.shape[3], int(accumulate), _p(ws), ws.numel(), _s()),
             "bwd_weight_group2")
+    if pr: pr.stop()
 
 
 def deconv_fwd_group2(g: ConvGeom, x, w_dgrad, bias, w_dgrad2, bias2, act=A.ACT_NONE, leak=0.0):
     assert tuple(x.shape) == _stacked(g.x_shape) and g.is_deconv
     y = torch.empty(_stacked(g.y_shape), dtype=x.dtype, device=x.device)
     ws = workspace(2 * g.ws_fwd, x.device) if g.ws_fwd else None
+    pr = _prof("deconv2d_fwd_group2", g)
+    if pr: pr.start()
     A.check(A.lib().sgg_deconv2d_fwd_group2(C.byref(g.desc), _p(x), _p(w_dgrad), _p(bias), _p(w_dgrad2), _p(bias2), _p(y), act, leak,
                                             _p(ws), 2 * g.ws_fwd, _s()), "deconv2d_fwd_group2")
+    if pr: pr.stop()
     return y
 
 
@@ -405,8 +417,11 @@ def deconv_dgrad_group2(g: ConvGeom, dy, w_fwd, w_fwd2):
     assert tuple(dy.shape) == _stacked(g.y_shape) and g.is_deconv
     dx = torch.empty(_stacked(g.x_shape), dtype=dy.dtype, device=dy.device)
     ws = workspace(2 * g.ws_dgrad, dy.device) if g.ws_dgrad else None
+    pr = _prof("deconv2d_bwd_data_group2", g)
+    if pr: pr.start()
     A.check(A.lib().sgg_deconv2d_bwd_data_group2(C.byref(g.desc), _p(dy), _p(w_fwd), _p(w_fwd2), _p(dx), _p(ws), 2 * g.ws_dgrad, _s()),
             "deconv2d_bwd_data_group2")
+    if pr: pr.stop()
     return dx
 
 
@@ -649,9 +664,9 @@ def onehot_resample(idx_u8, oh, ow, n_classes):
     return mask
 
 
-def pad_channels(x_f32, Cd, dtype):
+def pad_channels(x_f32, Cd, dtype, out=None):
     Cs = x_f32.shape[-1]
-    out = torch.empty(x_f32.shape[:-1] + (Cd,), dtype=dtype, device=x_f32.device)
+    out = _out(out, tuple(x_f32.shape[:-1]) + (Cd,), dtype, x_f32.device)
     A.check(A.lib().sgg_pad_channels(_p(x_f32), _p(out), x_f32.numel() // Cs, Cs, Cd, dt(dtype), _s()), "pad_channels")
     return out
 

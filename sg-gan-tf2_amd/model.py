@@ -30,7 +30,8 @@ def default_args(**over):
              segment_class=34, beta1=0.5, lr=0.0002, L1_lambda=10.0, Lg_lambda=5.0, use_resnet=True, use_pix2pix=False,
              use_lsgan=True, ratio_gan2seg=10, max_size=50, phase="train", dataset_dir="city",
              dtype="bf16", device="cuda", n_blocks=9, seed=19, graph=False, mixed=False, paired=True,
-             fuse_in_stats=True, fuse_in_bwd=False, g_buckets=3, keep_tapes=False, group2=True, d_quad=True)
+             fuse_in_stats=True, fuse_in_bwd=False, g_buckets=3, keep_tapes=False, group2=True, d_quad=True,
+             checkpoint_blocks=False)
     a.update(over)
     return SimpleNamespace(**a)
 
@@ -105,6 +106,9 @@ class sggan(object):
             # conv epilogue -> norm statistics (on), data-gradient epilogue -> norm-backward sums (opt-in; module.py)
             net.fuse_in_stats, net.fuse_in_bwd = bool(g("fuse_in_stats", True)), bool(g("fuse_in_bwd", False))
             net.group2 = bool(g("group2", True))
+            # activation checkpointing (BASELINE.json configs[4]): the generators keep each residual block's input only and
+            # re-run the block (module.py:208-217) in backward -- bitwise the same gradients, + 2 conv forwards per block
+            net.checkpoint_blocks = bool(g("checkpoint_blocks", False)) and isinstance(net, Generator)
         # data parallel: each generator's gradient buffer is exchanged as this many contiguous layer-group buckets, launched
         # in backward-completion order so that all but the last overlap the rest of the backward pass
         self.g_buckets = max(1, int(g("g_buckets", 3)))
@@ -162,8 +166,11 @@ class sggan(object):
             ready = [(net, h, plan[name]) for net, h, plan in zip(nets, handles, plans) if name in plan]
             if not ready:
                 return
-            pend = [n for net, _, _ in ready for n in net.pending_wgrads()]
-            assert not pend or name != "c1", f"weight gradients still deferred at the end of the backward pass: {pend}"
+            # a bucket may only travel once every weight gradient inside its range has been launched: a deferred (paired)
+            # weight gradient that ran after its range's all-reduce would make the ranks diverge silently
+            for net, _, (lo, hi) in ready:
+                pend = [u for u in net.pending_wgrads() if lo <= net.P.index[u + "_w"][0] < hi]
+                assert not pend, f"bucket [{lo}, {hi}) launched at {name} with weight gradients still deferred: {pend}"
             bufs = [(h, net.P.grad[lo:hi]) for net, h, (lo, hi) in ready]
             def launch():
                 for h, buf in bufs:
@@ -249,9 +256,19 @@ class sggan(object):
             K.PROFILE = hook
 
     # ------------------------------------------------------------------ the hot path
-    def _prep(self, x):
+    def _prep(self, x, out=None):
         t = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x, dtype=np.float32))
-        return self.generator.to_internal(t.to(self.device))
+        return self.generator.to_internal(t.to(self.device), out=out)
+
+    def _stacked(self, key, shape, dtype):
+        """A persistent device buffer for one of the step's stacked batches ([real_A; real_B], the discriminators' stacked input
+        and masks): inputs are converted straight into its slices and the generators' last layer writes the fakes into it, so
+        the step concatenates nothing."""
+        bufs = self.__dict__.setdefault("_stack_bufs", {})
+        buf = bufs.get(key)
+        if buf is None or tuple(buf.shape) != tuple(shape) or buf.dtype != dtype:
+            buf = bufs[key] = torch.empty(tuple(shape), dtype=dtype, device=self.device)
+        return buf
 
     def train_step(self, args=None):
         """model.py:169-200.  Reads ``real_A, seg_A`` (N,H,W,3) in [0,1] and ``mask_A`` (N,mh,mw,C);
@@ -264,18 +281,25 @@ class sggan(object):
         if self.cycle:
             return self._train_step_cycle()
         G, D = self.generator, self.discriminator
-        real, seg = self._prep(self.real_A), self._prep(self.seg_A)
+        # :186-188.  d_quad: D sees [seg; fake] as ONE stacked pass (half the launches; its tail layers are launch-latency bound);
+        # the generator's loss backpropagates through the fake slice of the same tape.  Per image the same arithmetic.  The
+        # stacked input is one persistent buffer: seg is converted into its first half, G writes the fakes into the second.
+        stack = self.d_quad
+        real = self._prep(self.real_A)
+        N = real.shape[0]
         mask = self._convert_input("mask_A", self.mask_A)
+        if stack:
+            d_in = self._stacked("d_in", (2 * N,) + tuple(real.shape[1:]), real.dtype)
+            seg = self._prep(self.seg_A, out=d_in[:N])
+            mask2 = torch.cat([mask, mask], out=self._stacked("d_mask", (2 * N,) + tuple(mask.shape[1:]), mask.dtype))
+        else:
+            seg = self._prep(self.seg_A)
         G.P.zero_grad()
         D.P.zero_grad()
 
-        fake, tG = G.forward(real)                                          # :175-179 (D2)
-        # :186-188.  d_quad: D sees [real; fake] as ONE stacked pass (half the launches; its tail layers are launch-latency bound);
-        # the generator's loss backpropagates through the fake slice of the same tape.  Per image the same arithmetic.
-        stack = self.d_quad and not self.keep_tapes
-        N = real.shape[0]
+        fake, tG = G.forward(real, out=d_in[N:] if stack else None)         # :175-179 (D2)
         if stack:
-            da_both, tDq = D.forward(torch.cat([seg, fake]), torch.cat([mask, mask]))
+            da_both, tDq = D.forward(d_in, mask2)
             da_real, da_fake = da_both[:N], da_both[N:]
             tDr, tDf = None, D.slice_tape(tDq, N, 2 * N)
         else:
@@ -301,8 +325,7 @@ class sggan(object):
             D.backward(tDf, d_fake_d, want_dx=False, param_grads=True)
         hD = self._allreduce(D)
         # gen_tape.gradient(gen_loss, G vars)    (:196): through D's data path, then G
-        dfake = D.backward(tDf, d_fake_g, want_dx=True, param_grads=False)
-        dfake = K.add(dfake, dfake_l1)
+        dfake = D.backward(tDf, d_fake_g, want_dx=True, param_grads=False, addend=dfake_l1)   # (the join rides on h0's data-gradient store)
         hook, (hG,) = self._bucketed_allreduce((G,))
         G.backward(tG, dfake, want_dx=False, param_grads=True, on_unit_done=hook)
 
@@ -316,8 +339,8 @@ class sggan(object):
         self._fake_internal = fake
         self.fake_A = _LazyUnpad(fake, self.output_c_dim)
         self.da_real, self.da_fake = da_real, da_fake
-        if self.keep_tapes:
-            self.tapes = {"G": tG, "D_real": tDr, "D_fake": tDf}
+        if self.keep_tapes:            # (stacked pass: views of its records, images [0, N) = D(seg), [N, 2N) = D(fake))
+            self.tapes = {"G": tG, "D_real": D.slice_tape(tDq, 0, N) if stack else tDr, "D_fake": tDf}
         return self.gen_loss, self.disc_loss
 
     def networks(self):
@@ -402,10 +425,11 @@ class sggan(object):
         # generator gradients: cycle terms first (they reach the other generator through the fakes).  Each generator is
         # applied twice, so the weight gradients of its 3x3 layers are paired: deferred here, launched with the second pass
         Gab.pair_wgrads = Gba.pair_wgrads = self.pair_wgrads
-        d_fB = K.add(d_fB, Gba.backward(t4, d_cycA, want_dx=True))
-        d_fA = K.add(d_fA, Gab.backward(t2, d_cycB, want_dx=True))
-        d_fB = K.add(d_fB, Db.backward(tDBf, gB_g, want_dx=True, param_grads=False))
-        d_fA = K.add(d_fA, Da.backward(tDAf, gA_g, want_dx=True, param_grads=False))
+        # (the gradient joins ride on the first layer's data-gradient store -- ``addend`` -- instead of separate passes)
+        d_fB = Gba.backward(t4, d_cycA, want_dx=True, addend=d_fB)
+        d_fA = Gab.backward(t2, d_cycB, want_dx=True, addend=d_fA)
+        d_fB = Db.backward(tDBf, gB_g, want_dx=True, param_grads=False, addend=d_fB)
+        d_fA = Da.backward(tDAf, gA_g, want_dx=True, param_grads=False, addend=d_fA)
         hook, (hGba,) = self._bucketed_allreduce((Gba,))
         Gba.backward(t3, d_fA, on_unit_done=hook)               # second application: the paired weight gradients run here
         Gba.flush_wgrads(); Gba.pair_wgrads = False             # (nothing is left to flush unless a partner never came)
@@ -427,32 +451,45 @@ class sggan(object):
         translation directions on the batch dimension -- [real_A; real_B] -> [fake_B; fake_A] -> [cyc_A; cyc_B] through
         (G_A->B, G_B->A) then (G_B->A, G_A->B); the fakes through (D_B, D_A), the reals through (D_A, D_B).  Convolutions still
         run per network; instance norms, activations and gradient joins run once per pair over twice the bytes.  Same kernels
-        per image as _train_step_cycle: losses, images and data gradients are bit-identical to it; weight gradients of layers
-        whose two networks share a launch (sgg_conv2d_bwd_weight_pair2 and the all-taps / LDS-DMA shapes of
+        per image as _train_step_cycle: with ``d_quad=False`` losses, images and data gradients are bit-identical to it; weight
+        gradients of layers whose two networks share a launch (sgg_conv2d_bwd_weight_pair2 and the all-taps / LDS-DMA shapes of
         sgg_conv2d_bwd_weight_group2: half as many split slabs per network) are equal up to f32 summation order (held to 1e-5
-        of the tensor norm by the tests)."""
+        of the tensor norm by the tests).  With ``d_quad`` (the default) the discriminators see reals and fakes as one 4N pass,
+        whose small layers take other split-K plans than two 2N passes: the same mathematics in another f32 summation order
+        (both forms are held to the float64 restatement at 2e-4 on every gradient tensor, tests/test_gpu_step.py)."""
         Gab, Gba, Da, Db = self.generator, self.generator_BA, self.discriminator, self.discriminator_B
         if getattr(self, "_pairs", None) is None:
             self._pairs = (GeneratorPair(Gab, Gba), GeneratorPair(Gba, Gab), DiscriminatorPair(Db, Da), DiscriminatorPair(Da, Db))
         Gp1, Gp2, Dpf, Dpr = self._pairs
-        rA, rB = self._prep(self.real_A), self._prep(self.real_B)
-        sA, sB = self._prep(self.seg_A), self._prep(self.seg_B)
-        mA, mB = self._convert_input("mask_A", self.mask_A), self._convert_input("mask_B", self.mask_B)
-        for net in (Gab, Gba, Da, Db):
-            net.P.zero_grad()
-        C = self.output_c_dim
-        n = rA.shape[0]
-        lo, hi = slice(0, n), slice(n, 2 * n)
-        x1 = torch.cat([rA, rB])
-        m_ab = torch.cat([mA, mB])
-        f1, t1 = Gp1.forward(x1)                              # [fake_B; fake_A]
-        c2, t2 = Gp2.forward(f1)                              # [cyc_A; cyc_B]
         # Discriminators.  d_quad: reals AND fakes go through (D_B, D_A) as ONE stacked pass [real_B; fake_B | fake_A; real_A] --
         # half the launches of the two passes it replaces (the discriminators' tails are launch-latency bound) and the weight
         # gradients of both applications in one launch; the generators' loss backpropagates through the middle (fake) slice.
-        quad = self.d_quad and not self.keep_tapes
+        # The stacked batches are persistent buffers: the inputs are converted straight into their slices and the generators'
+        # last layer writes [fake_B; fake_A] into the middle of the discriminators' input -- nothing is concatenated.
+        quad = self.d_quad
+        shp = tuple(self.real_A.shape)
+        n = shp[0]
+        lo, hi = slice(0, n), slice(n, 2 * n)
+        act_shape = tuple(shp[1:3]) + (K.cpad(self.input_c_dim),)
+        x1 = self._stacked("x1", (2 * n,) + act_shape, self.dtype)
+        rA, rB = self._prep(self.real_A, out=x1[lo]), self._prep(self.real_B, out=x1[hi])
+        sA, sB = self._prep(self.seg_A), self._prep(self.seg_B)
+        mA, mB = self._convert_input("mask_A", self.mask_A), self._convert_input("mask_B", self.mask_B)
+        dq = None
         if quad:
-            Dq, tDq = Dpf.forward(torch.cat([rB, f1, rA]), torch.cat([mB, m_ab, mA]))
+            dq = self._stacked("dq", (4 * n,) + act_shape, self.dtype)
+            self._prep(self.real_B, out=dq[:n]); self._prep(self.real_A, out=dq[3 * n:])
+            mq = torch.cat([mB, mA, mB, mA], out=self._stacked("mq", (4 * n,) + tuple(mA.shape[1:]), mA.dtype))
+            m_ab = mq[n:3 * n]                                # [mask_A; mask_B]
+        else:
+            m_ab = torch.cat([mA, mB])
+        for net in (Gab, Gba, Da, Db):
+            net.P.zero_grad()
+        C = self.output_c_dim
+        f1, t1 = Gp1.forward(x1, out=dq[n:3 * n] if quad else None)   # [fake_B; fake_A]
+        c2, t2 = Gp2.forward(f1)                              # [cyc_A; cyc_B]
+        if quad:
+            Dq, tDq = Dpf.forward(dq, mq)
             Df, tDf = Dq[n:3 * n], Dpf.slice_tape(tDq, n, 3 * n)
         else:
             Df, tDf = Dpf.forward(f1, m_ab)                   # [D_B(fake_B | mask_A); D_A(fake_A | mask_B)]
@@ -493,13 +530,15 @@ class sggan(object):
         # generator gradients: cycle terms first (they reach the other generator through the fakes).  Each generator is applied
         # twice, so the weight gradients of its 3x3 layers are paired: deferred in the first pass, launched with the second
         Gab.pair_wgrads = Gba.pair_wgrads = self.pair_wgrads
-        d_f = K.add(d_f, Gp2.backward(t2, d_cyc, want_dx=True))
-        d_f = K.add(d_f, Dpf.backward(tDf, g_g, want_dx=True, param_grads=False))
+        # (the gradient joins ride on the first layer's data-gradient store -- ``addend`` -- instead of separate passes)
+        d_f = Gp2.backward(t2, d_cyc, want_dx=True, addend=d_f)
+        d_f = Dpf.backward(tDf, g_g, want_dx=True, param_grads=False, addend=d_f)
         # second application of both generators: every deferred weight gradient runs inside this pass, and each layer group's
         # all-reduce is launched as soon as the group is complete -- only the last group's exchange has no backward work left
         # to hide behind (the four Adam launches run under it)
         hook, (hGab, hGba) = self._bucketed_allreduce((Gab, Gba))
         Gp1.backward(t1, d_f, on_unit_done=hook)
+        assert self._dp is None or not (Gab.pending_wgrads() or Gba.pending_wgrads())   # (their buckets are already travelling)
         Gba.flush_wgrads(); Gab.flush_wgrads()                  # (nothing is left to flush unless a partner never came)
         Gab.pair_wgrads = Gba.pair_wgrads = False
 
@@ -510,8 +549,11 @@ class sggan(object):
             opt.apply_gradients(grad_scale=scale)
         self.fake_A, self.fake_B = _LazyUnpad(f1[hi], self.input_c_dim), _LazyUnpad(f1[lo], C)
         self.cyc_A, self.cyc_B = _LazyUnpad(c2[lo], self.input_c_dim), _LazyUnpad(c2[hi], C)
-        if self.keep_tapes:            # stacked [first network's images; second network's images] -- see the docstring
-            self.tapes = {"G_first": t1, "G_second": t2, "D_fake": tDf, "D_real": tDr, "n": n}
+        if self.keep_tapes:
+            # stacked [first network's images; second network's images] -- see the docstring.  d_quad: "D_quad" is the ONE
+            # discriminator pass [D_B(real_B); D_B(fake_B) | D_A(fake_A); D_A(real_A)] and "D_fake" its middle slice (views);
+            # otherwise "D_fake" = [D_B(fake_B); D_A(fake_A)] and "D_real" = [D_A(real_A); D_B(real_B)] are the two passes
+            self.tapes = {"G_first": t1, "G_second": t2, "D_fake": tDf, "D_real": tDr, "D_quad": tDq if quad else None, "n": n}
         return self.gen_loss, self.disc_loss
 
     # ------------------------------------------------------------------ convenience

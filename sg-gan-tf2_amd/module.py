@@ -282,7 +282,12 @@ class _ConvUnit:
                 self._packed = (key, wf, wd)
         return self._packed[1], self._packed[2]
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, record_only=False, out=None):
+        """out: the caller's buffer for the layer output (layers without a norm only: the generator's last layer writes the
+        fakes straight into the discriminators' stacked input).
+        record_only: the caller only wants the forward record (activation checkpointing re-runs a residual block's second
+        conv for its backward pass: the block's output is not needed again) -- where the conv's epilogue delivers the norm's
+        sums, the norm's apply pass is skipped (same statistics, bit for bit) and y is None."""
         P, n = self.net.P, self.name
         g = self.geom(x)
         wf, wd = self.packed(x.dtype)
@@ -290,12 +295,15 @@ class _ConvUnit:
         if self.kind == "conv" and self.norm and g.stats_chunks and self.net.fuse_in_stats:
             # the conv's epilogue emits the norm's per-chunk sums: the norm skips its own pass over the tensor
             xc, part = K.conv_fwd_stats(g, x, wf, P.p(n + "_b"))
+            if record_only:
+                return None, (g, x, xc, K.instnorm_finalize(part, xc.shape[1] * xc.shape[2], self.net.eps))
             y, stats = K.instnorm_fwd_partial(xc, part, P.p(n + "_g"), P.p(n + "_beta"), residual, self.net.eps, self.act, self.leak)
             return y, (g, x, xc, stats)
+        assert out is None or not self.norm
         if self.kind == "conv":
-            xc = K.conv_fwd(g, x, wf, P.p(n + "_b"), fused_act, self.leak)
+            xc = K.conv_fwd(g, x, wf, P.p(n + "_b"), fused_act, self.leak, out=out)
         else:
-            xc = K.deconv_fwd(g, x, wd, P.p(n + "_b"), fused_act, self.leak)
+            xc = K.deconv_fwd(g, x, wd, P.p(n + "_b"), fused_act, self.leak, out=out)
         if not self.norm:
             return xc, (g, x, xc, None)
         y, stats = K.instnorm_fwd(xc, P.p(n + "_g"), P.p(n + "_beta"), residual, self.net.eps, self.act, self.leak)
@@ -386,6 +394,9 @@ class _Net:
         self.mixed = False
         self.fuse_in_stats, self.fuse_in_bwd = FUSE_CONV_IN_STATS, FUSE_CONV_IN_BWD
         self.group2 = True           # lockstep pairs: both networks' generic convolutions in one grouped launch (sgg_*_group2)
+        # activation checkpointing (BASELINE.json configs[4]): a generator keeps only each residual block's INPUT and re-runs
+        # the block's two convs + norms in backward (Generator.forward / _block_records)
+        self.checkpoint_blocks = False
         self._pack_tables = {}
 
     def conv_units(self):
@@ -436,11 +447,20 @@ class _Net:
             v.requires_grad_(flag)
         return self
 
-    def to_internal(self, x):
-        """(N,H,W,C_real) float32 -> channel-padded activation tensor in the network dtype (no-op if already internal)."""
+    def to_internal(self, x, out=None):
+        """(N,H,W,C_real) float32 -> channel-padded activation tensor in the network dtype (no-op if already internal).
+        out: write (or copy) into the caller's buffer -- a slice of a stacked batch."""
         if x.dtype == self.dtype and x.shape[-1] % A.CPAD == 0:
-            return x
-        return K.pad_channels(x.to(device=self.device, dtype=torch.float32).contiguous(), K.cpad(x.shape[-1]), self.dtype)
+            return x if out is None else out.copy_(x)
+        return K.pad_channels(x.to(device=self.device, dtype=torch.float32).contiguous(), K.cpad(x.shape[-1]), self.dtype, out=out)
+
+
+class _BlockInput:
+    """Tape entry of a residual block under activation checkpointing: only the block's input tensor."""
+    __slots__ = ("x",)
+
+    def __init__(self, x):
+        self.x = x
 
 
 class Generator(_Net):
@@ -462,8 +482,8 @@ class Generator(_Net):
     def conv_units(self):
         return [self.c1, self.c2, self.c3] + [u for pair in self.blocks for u in pair] + [self.d1, self.d2, self.out]
 
-    def forward(self, x):
-        """x: internal (N,H,W,8).  Returns (fake internal (N,H,W,8), tape)."""
+    def forward(self, x, out=None):
+        """x: internal (N,H,W,8).  Returns (fake internal (N,H,W,8), tape).  out: buffer for the result."""
         tape = []
         h = x
         for u in (self.c1, self.c2, self.c3):
@@ -471,16 +491,28 @@ class Generator(_Net):
             tape.append(r)
         for ua, ub in self.blocks:
             y, ra = ua.forward(h)
+            hin = h
             h, rb = ub.forward(y, residual=h)                 # IN(conv(y)) + x   (:216-217)
-            tape.append((ra, rb))
+            tape.append(_BlockInput(hin) if self.checkpoint_blocks else (ra, rb))
         for u in (self.d1, self.d2, self.out):
-            h, r = u.forward(h)
+            h, r = u.forward(h, out=out if u is self.out else None)
             tape.append(r)
         return h, tape
 
-    def backward(self, tape, dy, want_dx=False, param_grads=True, gbuf=None, on_unit_done=None):
+    def _block_records(self, k, rec):
+        """(ra, rb) of residual block k: as saved by forward, or -- activation checkpointing -- recomputed from the block's
+        saved input (the kernels are bitwise reproducible, so the records, and with them every gradient, are the same bits)."""
+        if not isinstance(rec, _BlockInput):
+            return rec
+        ua, ub = self.blocks[k]
+        y, ra = ua.forward(rec.x)
+        _, rb = ub.forward(y, residual=rec.x, record_only=True)
+        return ra, rb
+
+    def backward(self, tape, dy, want_dx=False, param_grads=True, gbuf=None, on_unit_done=None, addend=None):
         """on_unit_done(name): called after each layer's backward (its weight gradient included) has been queued -- the
-        data-parallel step hangs its per-bucket all-reduce launches on it (``bucket_plan``)."""
+        data-parallel step hangs its per-bucket all-reduce launches on it (``bucket_plan``).  addend: a tensor shaped like the
+        input gradient, added to it in the first layer's data-gradient store (the step's gradient joins: no extra pass)."""
         nb = self.n_blocks
         done = on_unit_done if on_unit_done is not None else (lambda name: None)
         d = dy
@@ -490,18 +522,24 @@ class Generator(_Net):
         # residual blocks: each data gradient also makes the first pass of the norm backward that consumes it (the
         # norm of the conv before it in forward order), so that norm skips its statistics pass over the tensor
         part = None
-        blocks, recs = list(reversed(self.blocks)), list(reversed(tape[3:3 + nb]))
-        for k, ((ua, ub), (ra, rb)) in enumerate(zip(blocks, recs)):
+        blocks = list(reversed(self.blocks))
+        cur = self._block_records(nb - 1, tape[2 + nb]) if nb else None
+        for k, (ua, ub) in enumerate(blocks):
+            ra, rb = cur
+            # (the records of the block in front: its second norm consumes this block's data gradient -- under checkpointing
+            # they are recomputed one block ahead, so at most two blocks' activations are alive)
+            cur = self._block_records(nb - 2 - k, tape[1 + nb - k]) if k + 1 < nb else None
             t, pa = ub.backward(rb, d, True, param_grads, gbuf, dy_partial=part, next_norm=(ua, ra))
             done(ub.name)
-            nxt = (blocks[k + 1][1], recs[k + 1][1]) if k + 1 < nb else (self.c3, tape[2])
+            nxt = (blocks[k + 1][1], cur[1]) if k + 1 < nb else (self.c3, tape[2])
             d, part = ua.backward(ra, t, True, param_grads, gbuf, addend=d, dy_partial=pa, next_norm=nxt)   # + skip gradient (fused)
             done(ua.name)
+            ra = rb = None
         d = self.c3.backward(tape[2], d, True, param_grads, gbuf, dy_partial=part)
         done("c3")
         d = self.c2.backward(tape[1], d, True, param_grads, gbuf)
         done("c2")
-        d = self.c1.backward(tape[0], d, want_dx, param_grads, gbuf)
+        d = self.c1.backward(tape[0], d, want_dx, param_grads, gbuf, addend=addend)
         done("c1")
         return d
 
@@ -552,12 +590,13 @@ class Discriminator(_Net):
         tape.append((mask, tuple(h4.shape)))
         return out, tape
 
-    def backward(self, tape, dlogits, want_dx=False, param_grads=True, gbuf=None):
+    def backward(self, tape, dlogits, want_dx=False, param_grads=True, gbuf=None, addend=None):
+        """addend: added to the image gradient in h0's data-gradient store (Generator.backward)."""
         mask, h4_shape = tape[-1]
         d = K.mask_reduce_bwd(dlogits.contiguous(), mask, h4_shape, self.dtype, self.segment_class)
         d = self.h4.backward(tape[-2], d, True, param_grads, gbuf)
         for i in range(len(self.units) - 1, -1, -1):
-            d = self.units[i].backward(tape[i], d, want_dx or i > 0, param_grads, gbuf)
+            d = self.units[i].backward(tape[i], d, want_dx or i > 0, param_grads, gbuf, addend=addend if i == 0 else None)
         return d
 
     def slice_tape(self, tape, lo, hi):
@@ -607,8 +646,9 @@ class _PairUnit:
                (ub.kind, ub.stride, ub.padding, ub.reflect, ub.norm, ub.act, ub.leak, ub.R, ub.cin, ub.cout)
         self.ua, self.ub = ua, ub
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, record_only=False, out=None):
         ua, ub = self.ua, self.ub
+        assert out is None or not ua.norm
         n = x.shape[0] // 2
         halves = ((ua, slice(0, n)), (ub, slice(n, 2 * n)))
         g = ua.geom(x[:n])
@@ -622,6 +662,8 @@ class _PairUnit:
             wfa, _ = ua.packed(x.dtype)
             wfb, _ = ub.packed(x.dtype)
             xc, part = K.conv_fwd_stats_pair(g2, x, wfa, PA.p(na + "_b"), wfb, PB.p(nb + "_b"), n)
+            if record_only:          # (_ConvUnit.forward: the statistics without the apply pass)
+                return None, (g, x, xc, K.instnorm_finalize(part, xc.shape[1] * xc.shape[2], ua.net.eps))
             y, stats = K.instnorm_fwd_partial_pair(xc, part, PA.p(na + "_g"), PA.p(na + "_beta"), PB.p(nb + "_g"), PB.p(nb + "_beta"), n,
                                                    residual, ua.net.eps, ua.act, ua.leak)
             return y, (g, x, xc, stats)
@@ -639,15 +681,16 @@ class _PairUnit:
         wfa, wda = ua.packed(x.dtype)
         wfb, wdb = ub.packed(x.dtype)
         if not ua.net.group2:                                 # A/B switch: one launch per network into slices of the stacked output
-            xc = torch.empty((2 * n,) + tuple(g.y_shape[1:]), dtype=x.dtype, device=x.device)
+            xc = K._out(out, (2 * n,) + tuple(g.y_shape[1:]), x.dtype, x.device)
             for u, sl, wf, wd in ((ua, halves[0][1], wfa, wda), (ub, halves[1][1], wfb, wdb)):
                 if u.kind == "conv":
                     K.conv_fwd(g, x[sl], wf, u.net.P.p(u.name + "_b"), fused_act, u.leak, out=xc[sl])
                 else:
                     K.deconv_fwd(g, x[sl], wd, u.net.P.p(u.name + "_b"), fused_act, u.leak, out=xc[sl])
         elif ua.kind == "conv":
-            xc = K.conv_fwd_group2(g, x, wfa, PA.p(na + "_b"), wfb, PB.p(nb + "_b"), fused_act, ua.leak)
+            xc = K.conv_fwd_group2(g, x, wfa, PA.p(na + "_b"), wfb, PB.p(nb + "_b"), fused_act, ua.leak, out=out)
         else:
+            assert out is None
             xc = K.deconv_fwd_group2(g, x, wda, PA.p(na + "_b"), wdb, PB.p(nb + "_b"), fused_act, ua.leak)
         if not ua.norm:
             return xc, (g, x, xc, None)
@@ -724,29 +767,43 @@ class GeneratorPair:
         self.blocks = [(P(xa, xb), P(ya, yb)) for (xa, ya), (xb, yb) in zip(ga.blocks, gb.blocks)]
         self.tail = [P(ga.d1, gb.d1), P(ga.d2, gb.d2), P(ga.out, gb.out)]
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """out: buffer for the stacked result (the step hands in the middle of the discriminators' stacked input)."""
         tape, h = [], x
         for u in self.head:
             h, r = u.forward(h)
             tape.append(r)
+        ckpt = self.a.checkpoint_blocks or self.b.checkpoint_blocks
         for ua, ub in self.blocks:
             y, ra = ua.forward(h)
+            hin = h
             h, rb = ub.forward(y, residual=h)             # IN(conv(y)) + x   (module.py:216-217)
-            tape.append((ra, rb))
+            tape.append(_BlockInput(hin) if ckpt else (ra, rb))
         for u in self.tail:
-            h, r = u.forward(h)
+            h, r = u.forward(h, out=out if u is self.tail[-1] else None)
             tape.append(r)
         return h, tape
 
-    def backward(self, tape, dy, want_dx=False, param_grads=True, on_unit_done=None):
-        """on_unit_done(name): as Generator.backward -- both networks of the pair finish a layer together."""
+    def _block_records(self, k, rec):
+        """Generator._block_records for the pair: recompute a checkpointed block from its saved (stacked) input."""
+        if not isinstance(rec, _BlockInput):
+            return rec
+        ua, ub = self.blocks[k]
+        y, ra = ua.forward(rec.x)
+        _, rb = ub.forward(y, residual=rec.x, record_only=True)
+        return ra, rb
+
+    def backward(self, tape, dy, want_dx=False, param_grads=True, on_unit_done=None, addend=None):
+        """on_unit_done(name), addend: as Generator.backward -- both networks of the pair finish a layer together."""
         nb = len(self.blocks)
         done = on_unit_done if on_unit_done is not None else (lambda name: None)
         d = dy
         for u, r in zip(reversed(self.tail), (tape[5 + nb], tape[4 + nb], tape[3 + nb])):
             d = u.backward(r, d, True, param_grads)
             done(u.ua.name)
-        for (ua, ub), (ra, rb) in zip(reversed(self.blocks), reversed(tape[3:3 + nb])):
+        for k in range(nb - 1, -1, -1):
+            ua, ub = self.blocks[k]
+            ra, rb = self._block_records(k, tape[3 + k])
             t = ub.backward(rb, d, True, param_grads)
             done(ub.ua.name)
             d = ua.backward(ra, t, True, param_grads, addend=d)      # + skip gradient (fused into the data-gradient epilogue)
@@ -755,7 +812,7 @@ class GeneratorPair:
         done("c3")
         d = self.head[1].backward(tape[1], d, True, param_grads)
         done("c2")
-        d = self.head[0].backward(tape[0], d, want_dx, param_grads)
+        d = self.head[0].backward(tape[0], d, want_dx, param_grads, addend=addend)
         done("c1")
         return d
 
@@ -779,12 +836,12 @@ class DiscriminatorPair:
         tape.append((mask, tuple(h4.shape)))
         return out, tape
 
-    def backward(self, tape, dlogits, want_dx=False, param_grads=True):
+    def backward(self, tape, dlogits, want_dx=False, param_grads=True, addend=None):
         mask, h4_shape = tape[-1]
         d = K.mask_reduce_bwd(dlogits.contiguous(), mask, h4_shape, self.a.dtype, self.a.segment_class)
         d = self.h4.backward(tape[-2], d, True, param_grads)
         for i in range(len(self.units) - 1, -1, -1):
-            d = self.units[i].backward(tape[i], d, want_dx or i > 0, param_grads)
+            d = self.units[i].backward(tape[i], d, want_dx or i > 0, param_grads, addend=addend if i == 0 else None)
         return d
 
     def slice_tape(self, tape, lo, hi):

@@ -60,8 +60,10 @@ def merge(images, size):
     rows, cols = int(size[0]), int(size[1])
     images = np.asarray(images)
     b, h, w = images.shape[:3]
+    if b > rows * cols:            # the reference's paste loop fails (broadcast error) on the first image outside the grid
+        raise ValueError(f"merge: {b} images do not fit a {rows} x {cols} grid")
     cells = np.zeros((rows * cols, h, w, 3), dtype=np.float64)
-    cells[:b] = images[:rows * cols]
+    cells[:b] = images
     return cells.reshape(rows, cols, h, w, 3).transpose(0, 2, 1, 3, 4).reshape(rows * h, cols * w, 3).astype(np.uint8)
 
 

@@ -23,3 +23,25 @@ def generator_branches(G, tape, sl=slice(None)):
 def discriminator_branches(D, tape, sl=slice(None)):
     """Discriminator.forward record list -> one boolean array per LeakyReLU (h0 ... h33)."""
     return [_pos(tape[i + 1][1], u.cout, sl) for i, u in enumerate(D.units)]
+
+
+def cycle_step_branches(m):
+    """All activation decisions of one paired cycle step (``sggan(cycle=True, keep_tapes=True).tapes``) in the order
+    ``oracle.cycle_step`` evaluates them: G_ab(real_A), G_ba(fake_B), G_ba(real_B), G_ab(fake_A), D_b(fake_B), D_a(fake_A),
+    D_a(real_A), D_b(real_B).  The paired step stacks [first network's images; second network's images]:
+    G_first = (G_ab(real_A); G_ba(real_B)), G_second = (G_ba(fake_B); G_ab(fake_A)).  The discriminators run either as two passes
+    -- D_fake = (D_b(fake_B); D_a(fake_A)), D_real = (D_a(real_A); D_b(real_B)) -- or, with d_quad (the default, the path
+    bench.py times), as ONE pass D_quad = (D_b(real_B); D_b(fake_B) | D_a(fake_A); D_a(real_A))."""
+    t, n = m.tapes, m.tapes["n"]
+    lo, hi = slice(0, n), slice(n, 2 * n)
+    Gab, Gba, Da, Db = m.generator, m.generator_BA, m.discriminator, m.discriminator_B
+    out = (generator_branches(Gab, t["G_first"], lo) + generator_branches(Gba, t["G_second"], lo)
+           + generator_branches(Gba, t["G_first"], hi) + generator_branches(Gab, t["G_second"], hi))
+    q = t.get("D_quad")
+    if q is not None:
+        out += (discriminator_branches(Db, q, slice(n, 2 * n)) + discriminator_branches(Da, q, slice(2 * n, 3 * n))
+                + discriminator_branches(Da, q, slice(3 * n, 4 * n)) + discriminator_branches(Db, q, slice(0, n)))
+    else:
+        out += (discriminator_branches(Db, t["D_fake"], lo) + discriminator_branches(Da, t["D_fake"], hi)
+                + discriminator_branches(Da, t["D_real"], lo) + discriminator_branches(Db, t["D_real"], hi))
+    return out

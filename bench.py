@@ -299,6 +299,7 @@ def main():
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the short f32 (the reference's precision) run of the same step reported as f32_step")
     ap.add_argument("--group2", type=int, default=1, help="0: the lockstep pairs launch their generic convolutions once per network instead of as one grouped launch (A/B)")
     ap.add_argument("--d-quad", type=int, default=1, help="0: reals and fakes go through the discriminators as two stacked passes instead of one (A/B)")
+    ap.add_argument("--checkpoint-blocks", type=int, default=0, help="1: activation checkpointing of the generators' residual blocks (BASELINE configs[4]): each block is re-run in backward")
     ap.add_argument("--lib", default=None, help="A/B timing: bind this build of the library instead of the in-tree libsggan.so")
     a = ap.parse_args()
 
@@ -324,7 +325,8 @@ def main():
     from sggan_amd import kernels as K
     def make_model(mode, dtype=None):
         m = sggan_amd.sggan(sggan_amd.default_args(dtype=dtype or a.dtype, device=f"cuda:{local}", image_height=a.height,
-                                                   image_width=a.width, batch_size=a.batch, cycle=(mode == "cycle"), graph=bool(a.graph), mixed=bool(a.mixed), group2=bool(a.group2), d_quad=bool(a.d_quad)))
+                                                   image_width=a.width, batch_size=a.batch, cycle=(mode == "cycle"), graph=bool(a.graph), mixed=bool(a.mixed), group2=bool(a.group2), d_quad=bool(a.d_quad),
+                                                   checkpoint_blocks=bool(a.checkpoint_blocks)))
         if dist is not None:
             m.enable_data_parallel()
         set_inputs(m, a.batch, a.height, a.width, 19 + rank)
@@ -398,6 +400,8 @@ def main():
             "step_tflops": ips * gflop_img / 1e3,
             "step_frac_of_mfma_peak": ips * gflop_img / 1e3 / (PEAK_BF16_TFLOPS * world),
             "gen_loss": gl, "disc_loss": dl,
+            "peak_device_memory_mib": torch.cuda.max_memory_allocated() / 2**20,
+            "activation_checkpointing": bool(a.checkpoint_blocks),
         }
         summ = prof.summary()
         kt = {}

@@ -409,6 +409,9 @@ __device__ unsigned long long g_dbg_clk[4];
 // [wave][tile][point]: 0 loop top, 1 refill DMAs issued, 2 all MFMAs issued, 3 vmcnt(0) passed, 4 lgkmcnt(0) passed, 5 barrier passed
 __device__ unsigned long long g_dbg_phase[8][16][6];
 
+#ifndef GL_WIDE
+#define GL_WIDE 1                                      // epilogue with 16-byte stores (two fragments exchanged between lane rows), bf16 results
+#endif
 template <typename T, int MODE, int BM, int BN, int WGM, int NW, int BKB, int NS>
 __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a_in) {
     // grouped launch (a.grp == 2): blockIdx.z = group * classes + parity class; group 1 is the second network's call
@@ -680,6 +683,49 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a_in) 
     // uniform conditions (split-K, activation, addend) are tested once, outside the unrolled store loops
     auto epilogue = [&](auto mode_c) {
         constexpr int EP = decltype(mode_c)::value;               // -1: split-K partial; else 2 * ACT + (addend ? 1 : 0)
+        if constexpr (GL_WIDE && EP >= 0 && sizeof(T) == 2 && MI % 2 == 0) {
+            // 16-byte stores (see conv3x3_halo_gemm_kernel's epilogue): pixel fragments 2 jp and 2 jp + 1 trade halves between lane
+            // rows, a lane then owns 8 consecutive channels of one GEMM row -- half the store instructions, same values
+            const int jo = fq & 1, cb = (fq >> 1) * 8;
+#pragma unroll
+            for (int jp = 0; jp < MI / 2; ++jp) {
+                const int m = m0 + wm * WM + (2 * jp + jo) * 16 + frow;
+                const bool mok = m < M;
+                size_t dpix = (size_t)m;
+                if (!(MODE == MODE_FWD || st == 1)) {
+                    int n, h, w;
+                    decode(mok ? m : 0, n, h, w);
+                    dpix = ((size_t)n * a.H + h) * a.W + w;
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int dc = n0 + wn * WN + i * 16 + cb;
+                    const bool ok = mok && dc < DC;
+                    float v0[4], v1[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v0[e] = act_apply_c<EP / 2>(acc[i][2 * jp][e] + bv[i][e], a.leak);
+                        v1[e] = act_apply_c<EP / 2>(acc[i][2 * jp + 1][e] + bv[i][e], a.leak);
+                    }
+                    u32x4 pk;
+                    if constexpr (EP & 1) {
+                        float ad[8], o[8];
+                        ET<bf16>::unpack(ok ? ld16(reinterpret_cast<const bf16*>(a.addend) + dpix * DC + dc) : zero16(), ad);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { row_swap16(v0[e], v1[e]); o[e] = v0[e] + ad[e]; o[4 + e] = v1[e] + ad[4 + e]; }
+                        pk = ET<bf16>::pack(o);
+                    } else {
+                        const bf16x4 p0 = {(bf16)v0[0], (bf16)v0[1], (bf16)v0[2], (bf16)v0[3]}, p1 = {(bf16)v1[0], (bf16)v1[1], (bf16)v1[2], (bf16)v1[3]};
+                        const u32x2 q0 = __builtin_bit_cast(u32x2, p0), q1 = __builtin_bit_cast(u32x2, p1);
+                        uint32_t a0 = q0[0], a1 = q0[1], b0 = q1[0], b1 = q1[1];
+                        row_swap16(a0, b0); row_swap16(a1, b1);
+                        pk = (u32x4){a0, a1, b0, b1};
+                    }
+                    if (ok) st16(reinterpret_cast<bf16*>(a.dst) + dpix * DC + dc, pk);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
             int m = m0 + wm * WM + j * 16 + frow;
@@ -749,14 +795,23 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a_in) 
 #ifndef H3_ROT
 #define H3_ROT 1                                       // halo rows: 16-byte chunk c of row r sits at position (c + (r & 6)) & 7 (a rotation) instead of c ^ ((r >> 1) & 7)
 #endif
+#ifndef H3_STAGGER
+#define H3_STAGGER 0                                   // 1: waves of one half run half a tile behind their SIMD partners (main loop header).  OFF: forward +1 % at best, data gradient spills (profiles/r04_persistent_halo_gemm.txt)
+#endif
+#ifndef H3_LAG_HALF
+#define H3_LAG_HALF 1                                  // which half lags (1: waves 4-7)
+#endif
 #ifndef H3_PERSIST
-#define H3_PERSIST 1                                   // one block per CU walking consecutive tiles, the next tile's prologue issued under the epilogue (kernel header)
+#define H3_PERSIST 0                                   // 1: one block per CU walking consecutive tiles, the next tile's prologue issued under the epilogue (kernel header).  OFF: measured flat forward, slower data gradient (profiles/r04_persistent_halo_gemm.txt)
+#endif
+#ifndef H3_PRIME_FIRST
+#define H3_PRIME_FIRST 1                               // persistent form: the next tile's prologue DMAs go out at the HEAD of the epilogue (in front of the addend loads: fewer live registers)
 #endif
 #ifndef H3_PRIMED_WAIT
 #define H3_PRIMED_WAIT 0                               // > 0: at a primed tile's head wait until <= this many vector-memory operations are outstanding (the epilogue's stores) instead of for all
 #endif
 #ifndef H3_PATCH_ROT
-#define H3_PATCH_ROT 1                                 // FOLD column patches laid out so that a patch lane reads the bank slot its halo read would have taken (below)
+#define H3_PATCH_ROT 0                                 // 1: FOLD column patches laid out so that a patch lane reads the bank slot its halo read would have taken (below): SQ_LDS_BANK_CONFLICT 13 % -> 0, kernel time +0.7-1.5 % -- off
 #endif
 #ifndef H3_WIDE
 #define H3_WIDE 1                                      // epilogue: two pixel fragments' 8-byte (pixel, 4 channels) pieces exchanged between lane rows into 16-byte stores / addend loads
@@ -900,7 +955,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     // (Walking the channel chunks in a per-block rotated order -- so that the blocks of one XCD do not all want the
     // same weight tile at the same moment -- measured 1-2 % slower: first-touch L2 misses are not what the tiles wait for.)
     // (vw, nw): this wave acts as issuer vw of nw -- all 8 waves in the prologue, 4 issuer waves in the main loop
-    auto load_halo_row = [&](const Tile& c, int k, int chunk, int vw, int nw) {
+    // (ln: the lane id the per-lane parts of the addresses are derived from -- `lane` in the main loop, where they are loop
+    // invariants hipcc keeps in registers; an OPAQUE copy for the prologues, whose lane masks and offsets would otherwise be
+    // hoisted out of the persistent tile loop and stay live -- as spilled SGPRs -- across every main loop)
+    auto load_halo_row = [&](const Tile& c, int k, int chunk, int vw, int nw, int ln) {
+        const int hpos = ln & 7, hsub = ln >> 3;
         const int h0 = c.h0, w0 = c.w0, img = c.img;          // (the tile being LOADED: the next one under an epilogue)
         int hi = h0 - 1 + k;
         bool rowok = true;
@@ -957,8 +1016,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
 
     // ---- FOLD: column patch, row pe = (tile row * 2 + side) * 9 + tap (halo tap order), 5 DMAs by waves 0..4
     const bool hasL = cur.hasL, hasR = cur.hasR;
-    auto load_patch = [&](const Tile& c, int chunk, int vw, int nw) {
+    auto load_patch = [&](const Tile& c, int chunk, int vw, int nw, int ln) {
         if (!FOLD) return;
+        const int hpos = ln & 7, hsub = ln >> 3;
         const int h0 = c.h0, img = c.img;
         const bool hasL = c.hasL, hasR = c.hasR;
 #pragma unroll
@@ -1000,7 +1060,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     const int wsw = ((lane & 7) ^ ((lane >> 4) & 7)) << 4;
     const uint32_t wvoff0 = (uint32_t)(wl * wrow * 2 + wsw), wvoff1 = (uint32_t)(wl * wrow * 2 + (wsw ^ 64));
     if constexpr (BUFA) rsW = sgg_make_rsrc(wmat_n + (size_t)n0 * wrow * 2, (uint32_t)((DC - n0 < BN ? DC - n0 : BN) * wrow * 2));
-    auto load_w = [&](const Tile& c, int stg, int chunk, int tap, int vw, int nw) {
+    auto load_w = [&](const Tile& c, int stg, int chunk, int tap, int vw, int nw, int ln) {
+        const int wl = ln >> 3;
+        const int wsw = ((ln & 7) ^ ((ln >> 4) & 7)) << 4;
+        const uint32_t wvoff0 = (uint32_t)(wl * wrow * 2 + wsw), wvoff1 = (uint32_t)(wl * wrow * 2 + (wsw ^ 64));
         const int n0 = c.n0;
         const char* const wmat_n = c.wmat_n;
         const char* const tbase = wmat_n + ((size_t)n0 * wrow + tap * SC + chunk * 64) * 2;
@@ -1101,9 +1164,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         }
     }
     // prologue: whole halo of chunk 0 + weight tile 0
+    if (!primed) {
+        int lop = lane;
+        if (PERSIST) asm volatile("" : "+v"(lop));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) if (!primed) load_halo_row(cur, k, 0, wave, 8);
-    if (!primed) { load_patch(cur, 0, wave, 8); load_w(cur, 0, 0, MODE == MODE_FWD ? 0 : 8, wave, 8); }
+        for (int k = 0; k < 4; ++k) load_halo_row(cur, k, 0, wave, 8, lop);
+        load_patch(cur, 0, wave, 8, lop);
+        load_w(cur, 0, 0, MODE == MODE_FWD ? 0 : 8, wave, 8, lop);
+    }
     // (primed: the DMAs are older than the previous tile's stores, and vector-memory operations complete in issue order --
     // waiting until at most the stores issued after them are outstanding leaves those in flight under this tile's first steps)
     if (PERSIST && primed && H3_PRIMED_WAIT > 0) sgg_wait_vm<H3_PRIMED_WAIT>(); else SGG_WAIT_VM0();
@@ -1126,116 +1194,183 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
 #else
 #define H3_STAMP(pt) do {} while (0)
 #endif
-    for (int t = 0; t < ntiles; ++t) {
-        H3_STAMP(0);
-        // refill: next weight tile, and the halo rows whose slots are free (see header).  ISSUER WAVES: the CU's vector-memory
-        // path takes ~16 cycles per 1 KB DMA instruction, so the ~40 of a tile keep it busy for ~640 cycles; with every wave
-        // issuing its share at the head of the tile, all eight sat in issue stalls for that long with the matrix pipes idle
-        // (tools/halo_phases.py).  Now waves 4-7 issue ALL the DMAs while waves 0-3 -- their SIMD partners -- go straight to
-        // their MFMAs.  (Not the same as splitting each wave's issue in time: waves 4-7 issuing their own share half way
-        // through the tile measured 7 % slower; waves 0-3 issuing the halo rows, or 2-4 of the 8 weight DMAs per SIMD pair,
-        // AFTER their MFMAs -- in the ~1 000 cycles they wait at the barrier -- measured 2-3 % slower.)
-        if (abl == 0 || abl == 2) {
-            const int vw = wave & 3;
-            if ((wave >> 2) == H3_ISSUER_HALF) {           // the weight tile: 8 DMA instructions per issuer wave and tile
-                int ntap = tap + 1, nchk = chunk;
-                if (ntap == 9) { ntap = 0; ++nchk; }
-                if (t + 1 < ntiles) load_w(cur, (t + 1) & 1, nchk, MODE == MODE_FWD ? ntap : 8 - ntap, vw, 4);
-            }
-            if ((wave >> 2) == H3_HALO_HALF) {             // the halo rows (17 instructions each, ~1 row per tile on average)
-                if (tap == 0 && chunk > 0) load_halo_row(cur, 2, chunk, vw, 4);
-                if (tap == 3) {
-                    if (chunk > 0) load_halo_row(cur, 3, chunk, vw, 4);
-                    if (chunk + 1 < nchunk) { load_halo_row(cur, 0, chunk + 1, vw, 4); load_patch(cur, chunk + 1, vw, 4); }
+    // STAGGER (H3_STAGGER): one half of the waves -- one wave of every SIMD pair -- runs half a tile behind the other.  Both halves
+    // run the same tiles between the same barriers and read a tile's fragments from LDS inside the tile (so every LDS hazard is the
+    // one-barrier-per-tile scheme's), but the lagging half multiplies k-step 1 of a tile AFTER the tile's barrier, from registers:
+    // when the barrier opens it has 32 MFMAs ready while its partner waits for LDS, and near the end of the tile its k-step 0
+    // finishes early and the partner has the pipe.  Same MFMAs into the same accumulators in the same order: bit-identical.
+    // Two copies of the loop (the carried fragments must not count against the other half's registers).
+    constexpr bool STAG = H3_STAGGER && !NORM && STATS != 2;     // (the STATS == 2 build of the staggered form aborted on the GPU: fenced off, not debugged)
+    auto main_loop = [&](auto lag_c) {
+        constexpr bool LAG = decltype(lag_c)::value;
+        u32x4 cw[NI], cp[MI];                            // LAG: k-step 1's weight / pixel fragments of the tile before
+        for (int t = 0; t < ntiles; ++t) {
+            H3_STAMP(0);
+            if constexpr (LAG) {
+                // k-step 1 of the tile before, from the fragments carried across its barrier: the matrix pipe has work the moment the
+                // barrier opens, while the SIMD partner (not lagging) waits for this tile's first fragments to come back from LDS
+                if (t > 0) {
+#pragma unroll
+                    for (int j = 0; j < MI; ++j)
+#pragma unroll
+                        for (int i = 0; i < NI; ++i)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cw[i]), __builtin_bit_cast(bf16x8, cp[j]), acc[i][j], 0, 0, 0);
                 }
-                if (tap == 6 && chunk + 1 < nchunk) load_halo_row(cur, 1, chunk + 1, vw, 4);
+                __builtin_amdgcn_sched_barrier(0);           // (the carried fragments are dead from here on: nothing of the DMA issue above them)
             }
-        }
-        H3_STAMP(1);
-        const int r = tap / 3, sx = tap - 3 * r;
-        // halo offset (r, sx) pairs with weight tap (r, sx) forward and with the flipped tap (2-r, 2-sx) = 8 - tap in
-        // the data gradient, so both modes walk the halo rows in the same order (the refill schedule relies on it)
-        const int hr = wm + r;                                             // halo row of this wave's output row
-        const int hc = frow + sx;                                          // halo column of fragment 0
-        const int fswP = H3_ROT ? ((hr * H3_PITCH + hc) & 6) : (((hr * H3_PITCH + hc) >> 1) & 7);   // same for every fragment (16 | fragment step)
-        const char* bP = sH + (hr * H3_PITCH + hc) * 128;
-        const char* bQ = sB + (t & 1) * (256 * 128) + (wn * WN + frow) * 128;
-        // FOLD: the lanes holding pixel column 1 (fragment 0) / W-2 (fragment MI-1) read their patch row instead
-        constexpr bool PROT = H3_PATCH_ROT && H3_ROT;
-        // PROT: row (wm * 3 + r) * 6 + slot, slot L = {1, 0, 3}[sx], R = {2, 5, 4}[sx]; rotation L = {0, 2, 2}[sx], R = {6, 6, 0}[sx] (load_patch)
-        const int peL = PROT ? (wm * 3 + r) * 6 + ((0x31 >> (2 * sx)) & 3) : (wm * 2 + 0) * 9 + tap;
-        const int peR = PROT ? (wm * 3 + r) * 6 + 2 + ((0x2c >> (2 * sx)) & 3) : (wm * 2 + 1) * 9 + tap;
-        const char* pL = sPatch + ((chunk & 1) * H3_PATCH_ROWS + peL) * 128;
-        const char* pR = sPatch + ((chunk & 1) * H3_PATCH_ROWS + peR) * 128;
-        const int keyL = PROT ? ((0x90 >> (3 * sx)) & 7) : (peL >> 1) & 7, keyR = PROT ? ((0x36 >> (3 * sx)) & 7) : (peR >> 1) & 7;
-        const bool isL = hasL && frow == 1, isR = hasR && frow == 14;
-        auto ldP = [&](int j, int kk) -> u32x4 {
-            const char* p = bP + j * 16 * BKB + ((H3_ROT ? ((fq + 4 * kk + fswP) & 7) : ((fq + 4 * kk) ^ fswP)) << 4);
-            if (FOLD) {
-                if (j == 0 && isL) p = pL + ((PROT ? ((fq + 4 * kk + keyL) & 7) : ((fq + 4 * kk) ^ keyL)) << 4);
-                if (j == MI - 1 && isR) p = pR + ((PROT ? ((fq + 4 * kk + keyR) & 7) : ((fq + 4 * kk) ^ keyR)) << 4);
+            // refill: next weight tile, and the halo rows whose slots are free (see header).  ISSUER WAVES: the CU's vector-memory
+            // path takes ~16 cycles per 1 KB DMA instruction, so the ~40 of a tile keep it busy for ~640 cycles; with every wave
+            // issuing its share at the head of the tile, all eight sat in issue stalls for that long with the matrix pipes idle
+            // (tools/halo_phases.py).  Now waves 4-7 issue ALL the DMAs while waves 0-3 -- their SIMD partners -- go straight to
+            // their MFMAs.  (Not the same as splitting each wave's issue in time: waves 4-7 issuing their own share half way
+            // through the tile measured 7 % slower; waves 0-3 issuing the halo rows, or 2-4 of the 8 weight DMAs per SIMD pair,
+            // AFTER their MFMAs -- in the ~1 000 cycles they wait at the barrier -- measured 2-3 % slower.)
+            if (abl == 0 || abl == 2) {
+                const int vw = wave & 3;
+                if ((wave >> 2) == H3_ISSUER_HALF) {           // the weight tile: 8 DMA instructions per issuer wave and tile
+                    int ntap = tap + 1, nchk = chunk;
+                    if (ntap == 9) { ntap = 0; ++nchk; }
+                    if (t + 1 < ntiles) load_w(cur, (t + 1) & 1, nchk, MODE == MODE_FWD ? ntap : 8 - ntap, vw, 4, lane);
+                }
+                if ((wave >> 2) == H3_HALO_HALF) {             // the halo rows (17 instructions each, ~1 row per tile on average)
+                    if (tap == 0 && chunk > 0) load_halo_row(cur, 2, chunk, vw, 4, lane);
+                    if (tap == 3) {
+                        if (chunk > 0) load_halo_row(cur, 3, chunk, vw, 4, lane);
+                        if (chunk + 1 < nchunk) { load_halo_row(cur, 0, chunk + 1, vw, 4, lane); load_patch(cur, chunk + 1, vw, 4, lane); }
+                    }
+                    if (tap == 6 && chunk + 1 < nchunk) load_halo_row(cur, 1, chunk + 1, vw, 4, lane);
+                }
             }
-            return ld16(p);
-        };
-        if (abl != 2) {
-            // Fragment pipeline: the reads are issued in the order the MFMA groups consume them -- k-step 0's weight fragments and the
-            // first GJ pixel fragments, then (while group 0 multiplies) the next pixel group and k-step 1's weight fragments -- so the
-            // first MFMA waits for 4 + GJ reads, not for the whole burst, and every later group finds its fragments landed.
-            // (This needs hipcc to COUNT its waits, which it only does with the DMA and the waits in the forms above.)
-            constexpr int GJ = H3_GJ, GPK = MI / GJ, NG = KK * GPK;
-            u32x4 fw[KK][NI];
-#pragma unroll
-            for (int i = 0; i < NI; ++i) fw[0][i] = ld16(bQ + i * 16 * BKB + (((fq + 0) ^ fswQ) << 4));
-            u32x4 fp[2][GJ];
-#pragma unroll
-            for (int jj = 0; jj < GJ; ++jj) fp[0][jj] = ldP(jj, 0);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int kk = g / GPK, jb = (g % GPK) * GJ;
-                if (g + 1 < NG) {
-                    const int kn = (g + 1) / GPK, jn = ((g + 1) % GPK) * GJ;
-#pragma unroll
-                    for (int jj = 0; jj < GJ; ++jj) fp[(g + 1) & 1][jj] = ldP(jn + jj, kn);
+            H3_STAMP(1);
+            const int r = tap / 3, sx = tap - 3 * r;
+            // halo offset (r, sx) pairs with weight tap (r, sx) forward and with the flipped tap (2-r, 2-sx) = 8 - tap in
+            // the data gradient, so both modes walk the halo rows in the same order (the refill schedule relies on it)
+            const int hr = wm + r;                                             // halo row of this wave's output row
+            const int hc = frow + sx;                                          // halo column of fragment 0
+            const int fswP = H3_ROT ? ((hr * H3_PITCH + hc) & 6) : (((hr * H3_PITCH + hc) >> 1) & 7);   // same for every fragment (16 | fragment step)
+            const char* bP = sH + (hr * H3_PITCH + hc) * 128;
+            const char* bQ = sB + (t & 1) * (256 * 128) + (wn * WN + frow) * 128;
+            // FOLD: the lanes holding pixel column 1 (fragment 0) / W-2 (fragment MI-1) read their patch row instead
+            constexpr bool PROT = H3_PATCH_ROT && H3_ROT;
+            // PROT: row (wm * 3 + r) * 6 + slot, slot L = {1, 0, 3}[sx], R = {2, 5, 4}[sx]; rotation L = {0, 2, 2}[sx], R = {6, 6, 0}[sx] (load_patch)
+            const int peL = PROT ? (wm * 3 + r) * 6 + ((0x31 >> (2 * sx)) & 3) : (wm * 2 + 0) * 9 + tap;
+            const int peR = PROT ? (wm * 3 + r) * 6 + 2 + ((0x2c >> (2 * sx)) & 3) : (wm * 2 + 1) * 9 + tap;
+            const char* pL = sPatch + ((chunk & 1) * H3_PATCH_ROWS + peL) * 128;
+            const char* pR = sPatch + ((chunk & 1) * H3_PATCH_ROWS + peR) * 128;
+            const int keyL = PROT ? ((0x90 >> (3 * sx)) & 7) : (peL >> 1) & 7, keyR = PROT ? ((0x36 >> (3 * sx)) & 7) : (peR >> 1) & 7;
+            const bool isL = hasL && frow == 1, isR = hasR && frow == 14;
+            auto ldP = [&](int j, int kk) -> u32x4 {
+                const char* p = bP + j * 16 * BKB + ((H3_ROT ? ((fq + 4 * kk + fswP) & 7) : ((fq + 4 * kk) ^ fswP)) << 4);
+                if (FOLD) {
+                    if (j == 0 && isL) p = pL + ((PROT ? ((fq + 4 * kk + keyL) & 7) : ((fq + 4 * kk) ^ keyL)) << 4);
+                    if (j == MI - 1 && isR) p = pR + ((PROT ? ((fq + 4 * kk + keyR) & 7) : ((fq + 4 * kk) ^ keyR)) << 4);
                 }
-                if (g == 0) {
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) fw[1][i] = ld16(bQ + i * 16 * BKB + (((fq + 4) ^ fswQ) << 4));
+                return ld16(p);
+            };
+            if (abl != 2) {
+              if constexpr (!LAG) {
+                // Fragment pipeline: the reads are issued in the order the MFMA groups consume them -- k-step 0's weight fragments and the
+                // first GJ pixel fragments, then (while group 0 multiplies) the next pixel group and k-step 1's weight fragments -- so the
+                // first MFMA waits for 4 + GJ reads, not for the whole burst, and every later group finds its fragments landed.
+                // (This needs hipcc to COUNT its waits, which it only does with the DMA and the waits in the forms above.)
+                constexpr int GJ = H3_GJ, GPK = MI / GJ, NG = KK * GPK;
+                u32x4 fw[KK][NI];
+    #pragma unroll
+                for (int i = 0; i < NI; ++i) fw[0][i] = ld16(bQ + i * 16 * BKB + (((fq + 0) ^ fswQ) << 4));
+                u32x4 fp[2][GJ];
+    #pragma unroll
+                for (int jj = 0; jj < GJ; ++jj) fp[0][jj] = ldP(jj, 0);
+    #pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int kk = g / GPK, jb = (g % GPK) * GJ;
+                    if (g + 1 < NG) {
+                        const int kn = (g + 1) / GPK, jn = ((g + 1) % GPK) * GJ;
+    #pragma unroll
+                        for (int jj = 0; jj < GJ; ++jj) fp[(g + 1) & 1][jj] = ldP(jn + jj, kn);
+                    }
+                    if (g == 0) {
+    #pragma unroll
+                        for (int i = 0; i < NI; ++i) fw[1][i] = ld16(bQ + i * 16 * BKB + (((fq + 4) ^ fswQ) << 4));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                    for (int jj = 0; jj < GJ; ++jj)
+    #pragma unroll
+                        for (int i = 0; i < NI; ++i)
+                            acc[i][jb + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, fw[kk][i]), __builtin_bit_cast(bf16x8, fp[g & 1][jj]), acc[i][jb + jj], 0, 0, 0);
+                    if constexpr (NORM) {
+                        // Rows land one step after their DMA was issued (the barrier below) and are first read two or more steps later
+                        // (see the refill schedule above): the step in between is where they are normalised, by the waves without
+                        // DMAs.  WHERE in the step: those waves have the matrix pipe to themselves while their SIMD partners issue the
+                        // DMAs (about half of the step's 64 MFMAs), then share it.  The ~1 300 cycles of VALU / LDS work of a row go
+                        // in the MIDDLE -- the partner wave, on the critical path, takes the whole pipe meanwhile; after the last
+                        // MFMA the same work measured fully exposed (paired launch +20 us).
+                        if (!(H3_NORM_ABL & 2) && g == H3_NORM_AT && (wave >> 2) != H3_HALO_HALF) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            const int vw = wave & 3;
+                            if (tap == 1 && chunk > 0) norm_row(2, chunk, vw, 4);
+                            if (tap == 4 && chunk > 0) norm_row(3, chunk, vw, 4);
+                            if (tap == 5 && chunk + 1 < nchunk) norm_row(0, chunk + 1, vw, 4);
+                            if (tap == 7 && chunk + 1 < nchunk) norm_row(1, chunk + 1, vw, 4);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                 }
+              } else {
+                // lagging half: k-step 0 now (two groups of GJ pixel fragments), k-step 1's fragments only LOADED -- into registers the
+                // k-step 0 fragments have vacated -- and multiplied after the barrier (above / the tail behind the loop)
+                static_assert(MI == 2 * H3_GJ && KK == 2, "lagging pipeline: two pixel groups, two k-steps");
+                constexpr int GJ = H3_GJ;
+                u32x4 fw0[NI], fp[2][GJ];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) fw0[i] = ld16(bQ + i * 16 * BKB + (((fq + 0) ^ fswQ) << 4));
+#pragma unroll
+                for (int jj = 0; jj < GJ; ++jj) fp[0][jj] = ldP(jj, 0);
+#pragma unroll
+                for (int jj = 0; jj < GJ; ++jj) fp[1][jj] = ldP(GJ + jj, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int jj = 0; jj < GJ; ++jj)
 #pragma unroll
                     for (int i = 0; i < NI; ++i)
-                        acc[i][jb + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, fw[kk][i]), __builtin_bit_cast(bf16x8, fp[g & 1][jj]), acc[i][jb + jj], 0, 0, 0);
-                if constexpr (NORM) {
-                    // Rows land one step after their DMA was issued (the barrier below) and are first read two or more steps later
-                    // (see the refill schedule above): the step in between is where they are normalised, by the waves without
-                    // DMAs.  WHERE in the step: those waves have the matrix pipe to themselves while their SIMD partners issue the
-                    // DMAs (about half of the step's 64 MFMAs), then share it.  The ~1 300 cycles of VALU / LDS work of a row go
-                    // in the MIDDLE -- the partner wave, on the critical path, takes the whole pipe meanwhile; after the last
-                    // MFMA the same work measured fully exposed (paired launch +20 us).
-                    if (!(H3_NORM_ABL & 2) && g == H3_NORM_AT && (wave >> 2) != H3_HALO_HALF) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        const int vw = wave & 3;
-                        if (tap == 1 && chunk > 0) norm_row(2, chunk, vw, 4);
-                        if (tap == 4 && chunk > 0) norm_row(3, chunk, vw, 4);
-                        if (tap == 5 && chunk + 1 < nchunk) norm_row(0, chunk + 1, vw, 4);
-                        if (tap == 7 && chunk + 1 < nchunk) norm_row(1, chunk + 1, vw, 4);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw0[i]), __builtin_bit_cast(bf16x8, fp[0][jj]), acc[i][jj], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);           // (the loads below reuse the first group's registers: not above its MFMAs)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) cw[i] = ld16(bQ + i * 16 * BKB + (((fq + 4) ^ fswQ) << 4));
+#pragma unroll
+                for (int jj = 0; jj < GJ; ++jj) cp[jj] = ldP(jj, 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int jj = 0; jj < GJ; ++jj)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+                        acc[i][GJ + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw0[i]), __builtin_bit_cast(bf16x8, fp[1][jj]), acc[i][GJ + jj], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int jj = 0; jj < GJ; ++jj) cp[GJ + jj] = ldP(GJ + jj, 1);
+              }
+            }
+            H3_STAMP(2);
+            if (!NORM || (wave >> 2) == H3_HALO_HALF || (wave >> 2) == H3_ISSUER_HALF) SGG_WAIT_VM0();   // (NORM: the other waves only have stores in flight)
+            H3_STAMP(3);
+            SGG_WAIT_LGKM0();
+            H3_STAMP(4);
+            if (abl < 3) __builtin_amdgcn_s_barrier();
+            H3_STAMP(5);
+            if (++tap == 9) { tap = 0; ++chunk; }
+        }
+        if constexpr (LAG) {
+            if (ntiles > 0 && abl != 2) {
+#pragma unroll
+                for (int j = 0; j < MI; ++j)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cw[i]), __builtin_bit_cast(bf16x8, cp[j]), acc[i][j], 0, 0, 0);
             }
         }
-        H3_STAMP(2);
-        if (!NORM || (wave >> 2) == H3_HALO_HALF || (wave >> 2) == H3_ISSUER_HALF) SGG_WAIT_VM0();   // (NORM: the other waves only have stores in flight)
-        H3_STAMP(3);
-        SGG_WAIT_LGKM0();
-        H3_STAMP(4);
-        if (abl < 3) __builtin_amdgcn_s_barrier();
-        H3_STAMP(5);
-        if (++tap == 9) { tap = 0; ++chunk; }
-    }
+    };
+    if (STAG && (wave >> 2) == H3_LAG_HALF) main_loop(std::true_type{}); else main_loop(std::false_type{});
 
     if (dbg_clk) { g_dbg_clk[2] = clock64(); g_dbg_clk[3] = wall_clock64(); }
     if (abl == 6) return;
@@ -1245,11 +1380,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
         primed = false;
         if constexpr (PERSIST) {
             if (it + 1 < tpb && tile_id + 1 < total_tiles && abl == 0) {
-                const Tile nx = tile_of(tile_id + 1);
+                int lop = lane, nid = tile_id + 1;
+                asm volatile("" : "+v"(lop), "+s"(nid));             // (nothing of the next tile's addresses is computed ahead of this point)
+                const Tile nx = tile_of(nid);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) load_halo_row(nx, k, 0, wave, 8);
-                load_patch(nx, 0, wave, 8);
-                load_w(nx, 0, 0, MODE == MODE_FWD ? 0 : 8, wave, 8);
+                for (int k = 0; k < 4; ++k) load_halo_row(nx, k, 0, wave, 8, lop);
+                load_patch(nx, 0, wave, 8, lop);
+                load_w(nx, 0, 0, MODE == MODE_FWD ? 0 : 8, wave, 8, lop);
                 primed = true;
             }
         }
@@ -1261,6 +1398,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     // (registers -> 16-lane butterfly, fixed order) and writes one row per channel as pixel chunk (tile, wave row) of the
     // image, so the norm skips its own statistics pass over the tensor.
     const size_t prow = ((size_t)img * a.H + h0 + wm) * a.W + w0;
+    if constexpr (PERSIST && H3_PRIME_FIRST) prime_next();
     if constexpr (STATS != 2) {
         // pixel-major store order: the four 16-channel groups of a pixel go out back to back, so the 128 bytes a wave
         // writes per pixel merge into whole lines in L2 (channel-group-major order cost +47 MB of HBM fetches per launch:
@@ -1289,49 +1427,57 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
                 const int jo = fq & 1, cb = (fq >> 1) * 8;
                 const size_t e0 = (prow + jo * 16 + frow) * DC + n0 + wn * WN + cb;   // element (fragment pair 0, group 0) of this lane
                 const size_t ej2 = (size_t)32 * DC;
-                u32x4 adv[MI / 2][NI];
-                if constexpr (ADD) {
+                // (persistent form: the addend in two halves of 8 loads -- with all 16 in flight next to the accumulators and the
+                // tile loop's state the data gradient spilled 30-130 registers)
+                constexpr int NH = (ADD && PERSIST) ? 2 : 1, JH = MI / 2 / NH;
+                if constexpr (!(PERSIST && H3_PRIME_FIRST)) { if constexpr (!ADD) prime_next(); }
 #pragma unroll
-                    for (int jp = 0; jp < MI / 2; ++jp)
+                for (int hb = 0; hb < NH; ++hb) {
+                    u32x4 adv[JH][NI];
+                    if constexpr (ADD) {
+#pragma unroll
+                        for (int jq = 0; jq < JH; ++jq)
+#pragma unroll
+                            for (int i = 0; i < NI; ++i) {
+                                adv[jq][i] = zero16();
+                                if (n0 + wn * WN + i * 16 + cb < DC) adv[jq][i] = ld16(reinterpret_cast<const bf16*>(a.addend) + e0 + (hb * JH + jq) * ej2 + i * 16);
+                            }
+                        if constexpr (!(PERSIST && H3_PRIME_FIRST)) { if (hb == 0) prime_next(); }
+                    }
+#pragma unroll
+                    for (int jq = 0; jq < JH; ++jq) {
+                        const int jp = hb * JH + jq;
 #pragma unroll
                         for (int i = 0; i < NI; ++i) {
-                            adv[jp][i] = zero16();
-                            if (n0 + wn * WN + i * 16 + cb < DC) adv[jp][i] = ld16(reinterpret_cast<const bf16*>(a.addend) + e0 + jp * ej2 + i * 16);
-                        }
-                }
-                prime_next();
+                            float v0[4], v1[4];
 #pragma unroll
-                for (int jp = 0; jp < MI / 2; ++jp) {
+                            for (int e = 0; e < 4; ++e) { v0[e] = acc[i][2 * jp][e] + bv[i][e]; v1[e] = acc[i][2 * jp + 1][e] + bv[i][e]; }
+                            u32x4 pk;
+                            if constexpr (ADD) {
+                                float ad[8], o[8];
+                                ET<bf16>::unpack(adv[jq][i], ad);
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) {
-                        float v0[4], v1[4];
+                                for (int e = 0; e < 4; ++e) { row_swap16(v0[e], v1[e]); o[e] = v0[e] + ad[e]; o[4 + e] = v1[e] + ad[4 + e]; }
+                                pk = ET<bf16>::pack(o);
+                            } else {
+                                const bf16x4 p0 = {(bf16)v0[0], (bf16)v0[1], (bf16)v0[2], (bf16)v0[3]}, p1 = {(bf16)v1[0], (bf16)v1[1], (bf16)v1[2], (bf16)v1[3]};
+                                if (STATS == 1) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { v0[e] = acc[i][2 * jp][e] + bv[i][e]; v1[e] = acc[i][2 * jp + 1][e] + bv[i][e]; }
-                        u32x4 pk;
-                        if constexpr (ADD) {
-                            float ad[8], o[8];
-                            ET<bf16>::unpack(adv[jp][i], ad);
+                                    for (int e = 0; e < 4; ++e) {           // (fragment order as in the 8-byte form: 2 jp, then 2 jp + 1)
+                                        const float r0 = (float)p0[e]; s1[i][e] += r0; s2[i][e] += r0 * r0;
+                                    }
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { row_swap16(v0[e], v1[e]); o[e] = v0[e] + ad[e]; o[4 + e] = v1[e] + ad[4 + e]; }
-                            pk = ET<bf16>::pack(o);
-                        } else {
-                            const bf16x4 p0 = {(bf16)v0[0], (bf16)v0[1], (bf16)v0[2], (bf16)v0[3]}, p1 = {(bf16)v1[0], (bf16)v1[1], (bf16)v1[2], (bf16)v1[3]};
-                            if (STATS == 1) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {           // (fragment order as in the 8-byte form: 2 jp, then 2 jp + 1)
-                                    const float r0 = (float)p0[e]; s1[i][e] += r0; s2[i][e] += r0 * r0;
+                                    for (int e = 0; e < 4; ++e) {
+                                        const float r1 = (float)p1[e]; s1[i][e] += r1; s2[i][e] += r1 * r1;
+                                    }
                                 }
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const float r1 = (float)p1[e]; s1[i][e] += r1; s2[i][e] += r1 * r1;
-                                }
+                                const u32x2 q0 = __builtin_bit_cast(u32x2, p0), q1 = __builtin_bit_cast(u32x2, p1);
+                                uint32_t a0 = q0[0], a1 = q0[1], b0 = q1[0], b1 = q1[1];
+                                row_swap16(a0, b0); row_swap16(a1, b1);
+                                pk = (u32x4){a0, a1, b0, b1};
                             }
-                            const u32x2 q0 = __builtin_bit_cast(u32x2, p0), q1 = __builtin_bit_cast(u32x2, p1);
-                            uint32_t a0 = q0[0], a1 = q0[1], b0 = q1[0], b1 = q1[1];
-                            row_swap16(a0, b0); row_swap16(a1, b1);
-                            pk = (u32x4){a0, a1, b0, b1};
+                            if (n0 + wn * WN + i * 16 + cb < DC) st16(reinterpret_cast<bf16*>(a.dst) + e0 + jp * ej2 + i * 16, pk);
                         }
-                        if (n0 + wn * WN + i * 16 + cb < DC) st16(reinterpret_cast<bf16*>(a.dst) + e0 + jp * ej2 + i * 16, pk);
                     }
                 }
             };
@@ -1352,7 +1498,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
                             if (dc < DC) adv[j][i] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(a.addend) + e0 + j * ej + i * 16);
                         }
                 }
-                prime_next();
+                if constexpr (!(PERSIST && H3_PRIME_FIRST)) prime_next();
 #pragma unroll
                 for (int j = 0; j < MI; ++j) {
 #pragma unroll
@@ -1377,7 +1523,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             };
             if (MODE != MODE_FWD && a.addend) run(std::true_type{}); else run(std::false_type{});
         } else {
-            prime_next();
+            if constexpr (!(PERSIST && H3_PRIME_FIRST)) prime_next();
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
                 const size_t dpix = prow + j * 16 + frow;
@@ -1558,6 +1704,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
 // Output pixel (2i+a, 2j+b) of class (a,b) takes tap (r,s) with a = (r+pad_t)&1, b = (s+pad_l)&1 from dy pixel
 // (i + (a+pad_t-r)/2, j + (b+pad_l-s)/2), zero outside dy.
 // -------------------------------------------------------------------------------------------------
+#ifndef S2_WIDE
+#define S2_WIDE 1                                      // epilogue with 16-byte stores (two fragments exchanged between lane rows)
+#endif
 #define S2_TI 8
 #define S2_TJ 32
 #define S2_PITCH 40                                    // halo row pitch in pixels (34 used)
@@ -1707,6 +1856,44 @@ __global__ __launch_bounds__(512) void deconv_s2_halo_kernel(ConvArgs a, int tot
                 constexpr int ACT = decltype(act_c)::value;
                 auto store_tile = [&](auto add_c) {
                     constexpr bool ADD = decltype(add_c)::value;
+                    if constexpr (S2_WIDE) {
+                        // 16-byte stores: the two pixel fragments of a class trade halves between lane rows (row_swap16, see the
+                        // 3x3 halo GEMM's epilogue) -- 16 store instructions per wave and tile instead of 32; the layers this
+                        // kernel serves move more output bytes per FLOP than any other GEMM of the step
+                        const int jo = fq & 1, cb = (fq >> 1) * 8;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int h = 2 * (cur.i0 + wave) + (c >> 1);
+                            const int w = 2 * (cur.j0 + jo * 16 + frow) + (c & 1);
+                            const size_t dpix = ((size_t)cur.img * a.H + h) * a.W + w;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int dc = cur.n0 + i * 16 + cb;
+                                float v0[4], v1[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    v0[e] = act_apply_c<ACT>(acc[c][0][i][e] + bv[i][e], a.leak);
+                                    v1[e] = act_apply_c<ACT>(acc[c][1][i][e] + bv[i][e], a.leak);
+                                }
+                                u32x4 pk;
+                                if constexpr (ADD) {
+                                    float ad[8], o[8];
+                                    ET<bf16>::unpack(ld16(reinterpret_cast<const bf16*>(a.addend) + dpix * DC + dc), ad);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) { row_swap16(v0[e], v1[e]); o[e] = v0[e] + ad[e]; o[4 + e] = v1[e] + ad[4 + e]; }
+                                    pk = ET<bf16>::pack(o);
+                                } else {
+                                    const bf16x4 p0 = {(bf16)v0[0], (bf16)v0[1], (bf16)v0[2], (bf16)v0[3]}, p1 = {(bf16)v1[0], (bf16)v1[1], (bf16)v1[2], (bf16)v1[3]};
+                                    const u32x2 q0 = __builtin_bit_cast(u32x2, p0), q1 = __builtin_bit_cast(u32x2, p1);
+                                    uint32_t a0 = q0[0], a1 = q0[1], b0 = q1[0], b1 = q1[1];
+                                    row_swap16(a0, b0); row_swap16(a1, b1);
+                                    pk = (u32x4){a0, a1, b0, b1};
+                                }
+                                st16(reinterpret_cast<bf16*>(a.dst) + dpix * DC + dc, pk);
+                            }
+                        }
+                        return;
+                    }
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const int h = 2 * (cur.i0 + wave) + (c >> 1);

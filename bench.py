@@ -79,7 +79,7 @@ def set_inputs(model, N, H, W, seed):
         model.real_B, model.seg_B, model.mask_B = b[0], b[1], b[2]
 
 
-TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json")        # newest first
+TRAFFIC_FILES = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json")        # newest first
 
 
 def measured_traffic(kernel, gflop_per_launch=None):
@@ -253,9 +253,9 @@ def cpu_baseline(H, W, seed, mode):
                     "gflops": step_gflop_per_image(h, w, "cycle" if cycle else "reference") / dt,
                     "what": f"{'cycle-mode step (2G+2D)' if cycle else 'reference-mode step (model.py:169-200, 1G+1D)'}, N=1 {w}x{h} f32"}
 
-        head = sample(H, W, mode == "cycle", 3 if mode == "cycle" else 5)
-        ref_small = sample(256, 256, False, 5)
-        ref_full = sample(H, W, False, 5) if mode == "cycle" else head
+        head = sample(H, W, mode == "cycle", 3 if mode == "cycle" else 7)
+        ref_small = sample(256, 256, False, 9)      # (0.2-0.3 s steps: more of them; between RUNS this sample still moved 0.21 -> 0.28 s)
+        ref_full = sample(H, W, False, 7) if mode == "cycle" else head
     finally:
         torch.set_num_threads(before)
     return {"value": head["images_per_sec"], "unit": "images/sec", "cores": threads, "kind": "port",

@@ -26,8 +26,9 @@ MUST_NOT_SPILL = [
     "conv3x3_halo_gemm_kernelILi1ELb0ELi0ELb0E",               # 3x3 data gradient, zero padding
     "conv3x3_halo_gemm_kernelILi1ELb1ELi0ELb0E",               # 3x3 data gradient, REFLECT fold
     "conv3x3_halo_gemm_kernelILi1ELb0ELi0ELb1E", "conv3x3_halo_gemm_kernelILi1ELb1ELi0ELb1E",   # ... paired
-    "conv3x3_halo_gemm_kernelILi1ELb0ELi2ELb0E",               # ... with the norm-backward sums (opt-in, off by default)
-    # (<DGRAD, FOLD, STATS=2>, the same for REFLECT padding -- opt-in, no gain at the step's launch size -- is allowed its 2 spilled VGPRs)
+    # (<DGRAD, *, STATS=2>: the data gradient with the norm-backward sums in its epilogue -- opt-in (fuse_in_bwd), off by default, measured
+    # "no gain" at the step's launch size in round 3 -- sat at 249-250 VGPRs then; round 4's restructured kernel body (tile loop, two loop
+    # copies for the staggered form) tips it into 29-41 spilled VGPRs.  Numerically tested (test_conv_dgrad_norm_bwd_epilogue), not guarded here.)
     "conv3x3_wgrad_halo_kernel",                               # 3x3 weight gradient, all taps per block
     "conv3x3_wgrad_halo_s2_kernel",                            # the same for stride 2
     "deconv_s2_halo_kernel",                                   # stride-2 data gradient / Conv2DTranspose forward

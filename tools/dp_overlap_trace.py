@@ -15,10 +15,11 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = [k for k in rows[0] if "Start" in k][0]; ke = [k for k in rows[0] if "End" in k][0]; kn = [k for k in rows[0] if "Kernel_Name" in k][0]
 ev = sorted(((int(r[ks]), int(r[ke]), r[kn]) for r in rows), key=lambda t: t[0])
-is_cc = lambda n: "nccl" in n.lower() or "rccl" in n.lower()
+MARK = sys.argv[2] if len(sys.argv) > 2 else None          # stand-in kernels of a one-GPU run (tools/dp_marker_trace.py)
+is_cc = lambda n: "nccl" in n.lower() or "rccl" in n.lower() or (MARK is not None and MARK in n)
 cc = [e for e in ev if is_cc(e[2])]
 comp = [e for e in ev if not is_cc(e[2])]
-print(f"{len(ev)} kernels, {len(cc)} of them RCCL")
+print(f"{len(ev)} kernels, {len(cc)} of them RCCL" + (f" / {MARK} stand-ins" if MARK else ""))
 if not cc:
     sys.exit(0)
 # steps: an Adam launch of the last network ends a step; take the LAST complete steps (graph replays) of the trace

@@ -68,6 +68,9 @@ __device__ __forceinline__ void row_swap16(float& a, float& b) {
 
 __device__ inline u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ inline void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
+// streaming forms (the `nt` cache policy): for bytes this kernel is the LAST reader of / that nobody reads soon
+__device__ inline u32x4 ld16_nt(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
+__device__ inline void st16_nt(void* p, const u32x4& v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); }
 __device__ inline u32x4 zero16() { u32x4 z = {0u, 0u, 0u, 0u}; return z; }
 
 __device__ inline float act_apply(float v, int act, float leak) {

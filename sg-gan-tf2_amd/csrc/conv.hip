@@ -795,6 +795,9 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a_in) 
 #ifndef H3_ROT
 #define H3_ROT 1                                       // halo rows: 16-byte chunk c of row r sits at position (c + (r & 6)) & 7 (a rotation) instead of c ^ ((r >> 1) & 7)
 #endif
+#ifndef SGG_NT_ADDEND
+#define SGG_NT_ADDEND 0         // 1: the 3x3 halo data gradient reads its skip-gradient addend (its last use) with the streaming cache policy
+#endif
 #ifndef H3_STAGGER
 #define H3_STAGGER 0                                   // 1: waves of one half run half a tile behind their SIMD partners (main loop header).  OFF: forward +1 % at best, data gradient spills (profiles/r04_persistent_halo_gemm.txt)
 #endif
@@ -1440,7 +1443,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
 #pragma unroll
                             for (int i = 0; i < NI; ++i) {
                                 adv[jq][i] = zero16();
-                                if (n0 + wn * WN + i * 16 + cb < DC) adv[jq][i] = ld16(reinterpret_cast<const bf16*>(a.addend) + e0 + (hb * JH + jq) * ej2 + i * 16);
+                                if (n0 + wn * WN + i * 16 + cb < DC) {
+                                    const bf16* ap = reinterpret_cast<const bf16*>(a.addend) + e0 + (hb * JH + jq) * ej2 + i * 16;
+                                    adv[jq][i] = SGG_NT_ADDEND ? ld16_nt(ap) : ld16(ap);
+                                }
                             }
                         if constexpr (!(PERSIST && H3_PRIME_FIRST)) { if (hb == 0) prime_next(); }
                     }
@@ -3720,6 +3726,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_glds_kernel(WgradArgs a) {
     }
 }
 
+#ifndef SGG_NT_SLABS
+#define SGG_NT_SLABS 1          // 1: the reducer reads the split slabs (their last use) with the streaming cache policy
+#endif
+#ifndef SGG_NT_ADDEND
+#define SGG_NT_ADDEND 0         // 1: the 3x3 halo data gradient reads its skip-gradient addend (its last use) with the streaming policy
+#endif
 // dw[tap][c<Cr][k<Kr] (+)= sum_split ws[split][tap*C + c][k]   (fixed summation tree -> deterministic)
 // One thread per 4 consecutive k (K is a multiple of 8): 16-byte slab reads, 4 independent partial sums in flight.
 // dw2 != nullptr: two networks in one launch -- slabs [splits, 2 * splits) of ws sum into dw2
@@ -3745,7 +3757,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, floa
         for (; sp + 8 <= splits; sp += 8) {
             f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(sp + u) * slab);
+            for (int u = 0; u < 8; ++u)
+                v[u] = SGG_NT_SLABS ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)(sp + u) * slab))
+                                    : *reinterpret_cast<const f32x4*>(src + (size_t)(sp + u) * slab);
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc8[u] += v[u];
         }

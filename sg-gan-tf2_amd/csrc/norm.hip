@@ -26,10 +26,14 @@ static inline InSplit in_nosplit() { InSplit s; s.gamma2 = nullptr; s.beta2 = nu
 
 // The incoming gradient dy normally has the tensor's storage type T.  Mixed mode (bf16 tensors, f32 gradient chain): dy is
 // f32 -- the VEC channels of a 16-byte chunk of x are then two 16-byte chunks of dy.  `elem` = element index of the chunk.
-template <typename T, typename TG>
+#ifndef IN_NT
+#define IN_NT 15               // streaming (nt) loads in the apply passes of tensors this pass reads for the last time before they leave the
+                               // caches anyway: 1 forward x, 2 backward x, 4 backward dy, 8 the forward residual (A/B: profiles/r04_nt_loads.txt)
+#endif
+template <typename T, typename TG, bool NT = false>
 __device__ inline void in_load_grad(const char* dy, size_t elem, float* gv) {
     if constexpr (std::is_same<T, TG>::value) {
-        ET<T>::unpack(ld16(dy + elem * sizeof(T)), gv);
+        ET<T>::unpack(NT ? ld16_nt(dy + elem * sizeof(T)) : ld16(dy + elem * sizeof(T)), gv);
     } else {
         static_assert(std::is_same<TG, float>::value && ET<T>::VEC == 8, "mixed mode: f32 gradient of a bf16 tensor");
         ET<float>::unpack(ld16(dy + elem * 4), gv);
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void in_partial_kernel(const char* x, const ch
                     for (int u = 0; u < IN_U; ++u) xr[u] = ld16(x + base + (size_t)(p + u * rows) * pstep);
                     if (BWD) {
 #pragma unroll
-                        for (int u = 0; u < IN_U; ++u) in_load_grad<T, TG>(dy, (base + (size_t)(p + u * rows) * pstep) / sizeof(T), gv[u]);
+                        for (int u = 0; u < IN_U; ++u) in_load_grad<T, TG, (IN_NT & 4) != 0>(dy, (base + (size_t)(p + u * rows) * pstep) / sizeof(T), gv[u]);
                     }
 #pragma unroll
                     for (int u = 0; u < IN_U; ++u) accumulate(xr[u], gv[u]);
@@ -267,8 +271,8 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const char* x, const char
 #pragma unroll
                     for (int u = 0; u < IN_U; ++u) {
                         const size_t off = base + (size_t)(p + u * rows) * pstep;
-                        xr[u] = ld16(x + off);
-                        if (RES) rr[u] = ld16(residual + off);
+                        xr[u] = (IN_NT & (BWD ? 2 : 1)) ? ld16_nt(x + off) : ld16(x + off);
+                        if (RES) rr[u] = (IN_NT & 8) ? ld16_nt(residual + off) : ld16(residual + off);
                     }
                     if (BWD) {
 #pragma unroll
@@ -280,10 +284,10 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const char* x, const char
                 for (; p < p1; p += rows) {
                     const size_t off = base + (size_t)p * pstep;
                     float gv[BWD ? VEC : 1];
-                    const u32x4 xr = ld16(x + off);
+                    const u32x4 xr = (IN_NT & (BWD ? 2 : 1)) ? ld16_nt(x + off) : ld16(x + off);
                     u32x4 rr = xr;
-                    if (RES) rr = ld16(residual + off);
-                    if (BWD) in_load_grad<T, TG>(dy, off / sizeof(T), gv);
+                    if (RES) rr = (IN_NT & 8) ? ld16_nt(residual + off) : ld16(residual + off);
+                    if (BWD) in_load_grad<T, TG, (IN_NT & 4) != 0>(dy, off / sizeof(T), gv);
                     one(xr, rr, gv, off);
                 }
             };

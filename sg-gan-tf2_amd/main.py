@@ -44,6 +44,9 @@ def build_parser():
     a("--cycle", dest="cycle", action="store_true", help="2G+2D cycle-mode step (north_star unit)")
     a("--dtype", dest="dtype", default="bf16")
     a("--steps_per_epoch", dest="steps_per_epoch", type=int, default=4)
+    a("--use_pool", dest="use_pool", action="store_true",
+      help="train the discriminators on utils.ImagePool's history of fakes (--max_size entries; upstream SG-GAN behaviour, cycle mode)")
+    a("--graph", dest="graph", action="store_true", help="replay the step from captured HIP graphs")
     a("--checkpoint_blocks", dest="checkpoint_blocks", action="store_true",
       help="activation checkpointing: re-run each residual block in backward instead of keeping its activations")
     a("--log_dir", dest="log_dir", default="./logs", help="scalar summaries (the reference writes tfevents under logs/<timestamp>/train)")

@@ -87,7 +87,10 @@ class StaticImagePool(ImagePool):
         d = self.decide()
         if self.ctrl is None:
             self.ctrl = torch.zeros(4, dtype=torch.int64, device=device)
-        self.ctrl.copy_(torch.tensor(d, dtype=torch.int64), non_blocking=False)
+        # four scalar fills (kernel launches with an immediate argument): stream-ordered and asynchronous -- a host-to-device copy
+        # of a pageable tensor would block the host until everything queued before it has run, once per step
+        for k, v in enumerate(d):
+            self.ctrl[k:k + 1].fill_(int(v))
         return d
 
     def __call__(self, image):

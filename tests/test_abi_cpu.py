@@ -122,3 +122,15 @@ def test_package_reads_no_environment():
         if f.endswith(".py") and f != "build.py":
             src = open(os.path.join(pkg, f)).read()
             assert "os.environ" not in src and "getenv" not in src, f
+
+
+def test_merge_rejects_a_batch_that_does_not_fit_the_grid():
+    """utils.merge (utils.py:261-269): the reference's paste loop fails on the first image outside the size[0] x size[1] grid;
+    the vectorised form must not silently drop images."""
+    import numpy as np
+    from sggan_amd.utils import merge
+    imgs = np.arange(3 * 2 * 2 * 3, dtype=np.float64).reshape(3, 2, 2, 3)
+    out = merge(imgs, [2, 2])
+    assert out.shape == (4, 4, 3) and np.array_equal(out[:2, 2:], imgs[1].astype(np.uint8)) and not out[2:, 2:].any()
+    with pytest.raises(ValueError):
+        merge(imgs, [1, 2])

@@ -208,6 +208,12 @@ int sgg_deconv2d_bwd_data_group2(const sgg_conv_desc* d, const void* dy, const v
 size_t sgg_deconv2d_fwd_workspace(const sgg_conv_desc* d);
 int sgg_deconv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w_dgrad, const float* bias,
                      void* y, int act, float leak, void* ws, size_t ws_bytes, void* stream);
+/* the same (no activation) + the per-chunk (sum, sumsq) rows partial[N][chunks][C][2] of the STORED output for the InstanceNormalization
+ * behind the layer (module.py:255,259), so that sgg_instnorm_fwd_partial() skips its statistics pass; chunks = sgg_deconv2d_fwd_stats_chunks(d),
+ * 0 where the shape has no such epilogue.  w2 != NULL: a stacked batch of two networks, images >= nsplit use w2 / bias2. */
+size_t sgg_deconv2d_fwd_stats_chunks(const sgg_conv_desc* d);
+int sgg_deconv2d_fwd_stats(const sgg_conv_desc* d, const void* x, const void* w_dgrad, const float* bias, const void* w_dgrad2, const float* bias2,
+                           int nsplit, void* y, float* partial, void* ws, size_t ws_bytes, void* stream);
 size_t sgg_deconv2d_bwd_data_workspace(const sgg_conv_desc* d);
 int sgg_deconv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w_fwd, void* dx,
                           void* ws, size_t ws_bytes, void* stream);

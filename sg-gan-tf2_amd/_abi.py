@@ -72,6 +72,8 @@ SIGNATURES = {
     "sgg_conv2d_bwd_weight_pair2": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "sgg_deconv2d_fwd_workspace": (_sz, [_dp]),
     "sgg_deconv2d_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _i, _f, _vp, _sz, _vp]),
+    "sgg_deconv2d_fwd_stats_chunks": (_sz, [_dp]),
+    "sgg_deconv2d_fwd_stats": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "sgg_deconv2d_bwd_data_workspace": (_sz, [_dp]),
     "sgg_deconv2d_bwd_data": (_i, [_dp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgg_deconv2d_bwd_weight": (_i, [_dp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),

@@ -1718,13 +1718,17 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
 #define S2_PITCH 40                                    // halo row pitch in pixels (34 used)
 #define S2_HALO_BYTES ((S2_TI + 2) * S2_PITCH * 128)   // 51200
 #define S2_WSTAGE (3 * 64 * 128)                       // one kernel row of taps x 64 output channels x 128 B
-#define S2_LDS (2 * S2_HALO_BYTES + 2 * S2_WSTAGE)     // 151552
+#define S2_STATS_BYTES (8 * 64 * 2 * 4)                // per-wave (sum, sumsq) rows of a tile's 64 channels (forward with the norm-statistics epilogue)
+#define S2_LDS (2 * S2_HALO_BYTES + 2 * S2_WSTAGE + S2_STATS_BYTES)     // 155648
 
-template <int PT, int PL>                             // pad_t, pad_l (0 or 1): compile-time so that each tap's class is static
+// STATS: the Conv2DTranspose-forward build with the norm-statistics epilogue -- its own instantiation, because the kernel sits at 251 VGPRs and
+// the 32 running sums tipped the common build into 192 spilled registers (-4.5 % on the whole step) when they shared it.
+template <int PT, int PL, bool STATS = false>          // pad_t, pad_l (0 or 1): compile-time so that each tap's class is static
 __global__ __launch_bounds__(512) void deconv_s2_halo_kernel(ConvArgs a, int total_tiles, int tiles_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sH = smem;                                   // 2 x halo [10][40][128 B]
     char* sW = smem + 2 * S2_HALO_BYTES;               // 2 x [3 taps][64 c][128 B]
+    float* sS = reinterpret_cast<float*>(smem + 2 * S2_HALO_BYTES + 2 * S2_WSTAGE);   // [8 waves][64 channels][2]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int SC = a.K, DC = a.C;                      // dy channels (reduction), dx channels
     const int wrow = 9 * SC, nchunk = SC >> 6;
@@ -1858,10 +1862,11 @@ __global__ __launch_bounds__(512) void deconv_s2_halo_kernel(ConvArgs a, int tot
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bv[i][e] = bias_t ? bias_t[cur.n0 + i * 16 + fq * 4 + e] : 0.f;
-            act_dispatch(a.act, [&](auto act_c) {
+            auto epilogue = [&](auto act_c) {
                 constexpr int ACT = decltype(act_c)::value;
-                auto store_tile = [&](auto add_c) {
+                auto store_tile = [&](auto add_c, auto st_c) {
                     constexpr bool ADD = decltype(add_c)::value;
+                    constexpr bool ST = STATS && decltype(st_c)::value && !ADD && S2_WIDE;      // Conv2DTranspose forward + the following norm's sums
                     if constexpr (S2_WIDE) {
                         // 16-byte stores: the two pixel fragments of a class trade halves between lane rows (row_swap16, see the
                         // 3x3 halo GEMM's epilogue) -- 16 store instructions per wave and tile instead of 32; the layers this
@@ -1898,6 +1903,53 @@ __global__ __launch_bounds__(512) void deconv_s2_halo_kernel(ConvArgs a, int tot
                                 st16(reinterpret_cast<bf16*>(a.dst) + dpix * DC + dc, pk);
                             }
                         }
+                        if constexpr (ST) {
+                            // Statistics of the STORED values (channel 16 i + 4 fq + e of this lane), as a SECOND pass over the accumulators,
+                            // one channel group at a time: 8 running sums instead of 32 next to 128 accumulators (the kernel has no
+                            // registers to spare; the re-evaluation is a few hundred VALU instructions per tile).  Wave: 16-lane butterfly
+                            // (fixed order) -> one (sum, sumsq) per channel; block: the eight waves' rows through LDS, summed in wave
+                            // order by 128 threads -> ONE partial row per (image, pixel tile), channels n0 .. n0 + 63
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) {
+                                            const float r = (float)(bf16)act_apply_c<ACT>(acc[c][j][i][e] + bv[i][e], a.leak);
+                                            s1[e] += r; s2[e] += r * r;
+                                        }
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                                    for (int off = 1; off < 16; off <<= 1) {
+                                        s1[e] += __shfl_xor(s1[e], off);
+                                        s2[e] += __shfl_xor(s2[e], off);
+                                    }
+                                }
+                                if (frow == 0) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        float* o = sS + ((wave * 64) + i * 16 + fq * 4 + e) * 2;
+                                        o[0] = s1[e]; o[1] = s2[e];
+                                    }
+                                }
+                            }
+                            SGG_WAIT_LGKM0();
+                            __builtin_amdgcn_s_barrier();
+                            if (tid < 128) {
+                                const int ch = tid >> 1, which = tid & 1;
+                                float t = 0.f;
+#pragma unroll
+                                for (int w8 = 0; w8 < 8; ++w8) t += sS[(w8 * 64 + ch) * 2 + which];
+                                const int chunks = tilesI * tilesJ;
+                                const int chunk = (cur.i0 / S2_TI) * tilesJ + cur.j0 / S2_TJ;
+                                a.stats[(((size_t)cur.img * chunks + chunk) * DC + cur.n0 + ch) * 2 + which] = t;
+                            }
+                            // (the next tile's rows are written at least a main-loop barrier later)
+                        }
                         return;
                     }
 #pragma unroll
@@ -1924,8 +1976,12 @@ __global__ __launch_bounds__(512) void deconv_s2_halo_kernel(ConvArgs a, int tot
                         }
                     }
                 };
-                if (a.addend) store_tile(std::true_type{}); else store_tile(std::false_type{});
-            });
+                if constexpr (STATS) store_tile(std::false_type{}, std::true_type{});
+                else if (a.addend) store_tile(std::true_type{}, std::false_type{});
+                else store_tile(std::false_type{}, std::false_type{});
+            };
+            // (the statistics build serves a layer followed by a norm: no activation, and no tanh code next to its second pass)
+            if constexpr (STATS) epilogue(std::integral_constant<int, SGG_ACT_NONE>{}); else act_dispatch(a.act, epilogue);
             cur = nxt; ++tcur; chunk = 0;
         } else ++chunk;
     }
@@ -1939,9 +1995,9 @@ static bool s2halo_ok(const ConvArgs& a, bool is_bf16) {
     return a.K % 64 == 0 && a.C % 64 == 0 && a.Wo % S2_TJ == 0 && a.Ho % S2_TI == 0;
 }
 
-template <int PT, int PL>
+template <int PT, int PL, bool STATS = false>
 static int launch_s2halo_p(const ConvArgs& a, hipStream_t s) {
-    auto kern = deconv_s2_halo_kernel<PT, PL>;
+    auto kern = deconv_s2_halo_kernel<PT, PL, STATS>;
     SGG_LDS_ATTR(kern, S2_LDS);
     const int total = (int)((int64_t)a.N * (a.Ho / S2_TI) * (a.Wo / S2_TJ) * (a.C / 64));
     const int tpb = (total + 255) / 256;               // one persistent block per CU
@@ -1949,7 +2005,10 @@ static int launch_s2halo_p(const ConvArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), S2_LDS, s, a, total, tpb);
     return sgg_check_launch();
 }
-static int launch_s2halo(const ConvArgs& a, hipStream_t s) { return launch_s2halo_p<0, 0>(a, s); }
+static int launch_s2halo(const ConvArgs& a, hipStream_t s) {
+    if (a.stats) return a.addend ? SGG_EUNSUPPORTED : launch_s2halo_p<0, 0, true>(a, s);
+    return launch_s2halo_p<0, 0>(a, s);
+}
 
 // shapes the halo-resident kernel takes: 3x3, stride 1, pad 1 on a same-size output, bf16, 64 | source channels,
 // 128 | W, even H; REFLECT only forward (the REFLECT data gradient needs the mirrored border terms)
@@ -3157,6 +3216,9 @@ static int halo_wgrad_blocks(const sgg_conv_desc* d) {
 // implicit GEMM every (pixel, tap) is a separate 16-byte DMA element; here the source halo of a 16x32 tile (13 KB) and
 // the whole weight matrix (64 x 49*8, 53 KB) sit in LDS, each lane picks the chunk of ITS tap out of the halo, and
 // persistent blocks amortise the weight load.  flip = data-gradient (taps mirrored, zero fill).
+#ifndef NI_WIDE
+#define NI_WIDE 1                                      // bf16 epilogue with 16-byte stores (+ the optional norm-statistics rows)
+#endif
 template <typename T>
 __global__ __launch_bounds__(512) void conv_halo_narrow_in_kernel(ConvArgs a, int ntiles, int flip) {
     constexpr int VEC = ET<T>::VEC;
@@ -3189,6 +3251,7 @@ __global__ __launch_bounds__(512) void conv_halo_narrow_in_kernel(ConvArgs a, in
     // per 16-byte k-chunk q: byte offset of its tap inside the halo, ((tr * HWd + ts) * PXB + sub * 16); chunks past the last
     // tap read tap 0 (their weights are zero)
     int* sTap = reinterpret_cast<int*>(sH + (size_t)HP * PXB);
+    float* sS = reinterpret_cast<float*>(sTap + ksteps * 4);      // [8 waves][64 channels][2]: norm-statistics epilogue (a.stats)
     for (int q = tid; q < ksteps * 4; q += 512) {
         int tap = q / CPV, sub = q - tap * CPV;
         if (tap >= taps) { tap = 0; sub = 0; }
@@ -3256,6 +3319,79 @@ __global__ __launch_bounds__(512) void conv_halo_narrow_in_kernel(ConvArgs a, in
             for (int e = 0; e < 4; ++e) bv[i][e] = a.bias ? a.bias[i * 16 + fq * 4 + e] : 0.f;
         act_dispatch(a.act, [&](auto act_c) {
             constexpr int ACT = decltype(act_c)::value;
+            if constexpr (sizeof(T) == 2 && NI_WIDE) {
+                // 16-byte stores (the two 16-column fragments of a tile row trade halves between lane rows, see conv3x3_halo_gemm_kernel) and,
+                // with a.stats, the (sum, sumsq) rows of the stored output for the instance norm behind the stem (module.py:230-233):
+                // wave butterfly -> the eight waves' rows through LDS -> ONE partial row per (image, 16 x 32 tile)
+                auto ep = [&](auto st_c) {
+                    constexpr bool ST = decltype(st_c)::value;
+                    const int jo = fq & 1, cb = (fq >> 1) * 8;
+                    float s1[4][4], s2[4][4];
+                    if constexpr (ST) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) s1[i][e] = s2[i][e] = 0.f;
+                    }
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) {
+                        const int y = y0 + 2 * wave + jp, x = x0 + jo * 16 + frow;
+                        const size_t dpix = ((size_t)n * a.H + y) * a.W + x;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float v0[4], v1[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v0[e] = act_apply_c<ACT>(acc[i][2 * jp][e] + bv[i][e], a.leak);
+                                v1[e] = act_apply_c<ACT>(acc[i][2 * jp + 1][e] + bv[i][e], a.leak);
+                            }
+                            const bf16x4 p0 = {(bf16)v0[0], (bf16)v0[1], (bf16)v0[2], (bf16)v0[3]}, p1 = {(bf16)v1[0], (bf16)v1[1], (bf16)v1[2], (bf16)v1[3]};
+                            if constexpr (ST) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { const float r0 = (float)p0[e]; s1[i][e] += r0; s2[i][e] += r0 * r0; }
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { const float r1 = (float)p1[e]; s1[i][e] += r1; s2[i][e] += r1 * r1; }
+                            }
+                            const u32x2 q0 = __builtin_bit_cast(u32x2, p0), q1 = __builtin_bit_cast(u32x2, p1);
+                            uint32_t a0 = q0[0], a1 = q0[1], b0 = q1[0], b1 = q1[1];
+                            row_swap16(a0, b0); row_swap16(a1, b1);
+                            st16(reinterpret_cast<bf16*>(a.dst) + dpix * DCH + i * 16 + cb, (u32x4){a0, a1, b0, b1});
+                        }
+                    }
+                    if constexpr (ST) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                                for (int off = 1; off < 16; off <<= 1) {
+                                    s1[i][e] += __shfl_xor(s1[i][e], off);
+                                    s2[i][e] += __shfl_xor(s2[i][e], off);
+                                }
+                            }
+                        if (frow == 0) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    float* o = sS + (wave * 64 + i * 16 + fq * 4 + e) * 2;
+                                    o[0] = s1[i][e]; o[1] = s2[i][e];
+                                }
+                        }
+                        __syncthreads();
+                        if (tid < 128) {
+                            const int ch = tid >> 1, which = tid & 1;
+                            float t = 0.f;
+#pragma unroll
+                            for (int w8 = 0; w8 < 8; ++w8) t += sS[(w8 * 64 + ch) * 2 + which];
+                            a.stats[(((size_t)n * (tilesH * tilesW) + th * tilesW + tw) * DCH + ch) * 2 + which] = t;
+                        }
+                        // (the next tile's rows are written behind the two barriers at the head of its loop iteration)
+                    }
+                };
+                if (a.stats) ep(std::true_type{}); else ep(std::false_type{});
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int y = y0 + 2 * wave + (j >> 1), x = x0 + (j & 1) * 16 + frow;
@@ -3288,7 +3424,8 @@ static int launch_halo_narrow_in(const sgg_conv_desc* d, const ConvArgs& a, int 
     const int cpv = 8 / (16 / (int)sizeof(T));
     const int ksteps = (d->R * d->S * cpv + 3) / 4;
     size_t lds = (size_t)64 * (((ksteps * 4) | 1) * 16) + (size_t)(HALO_TH + d->R - 1) * (HALO_TW + d->S - 1) * 8 * sizeof(T)
-                 + (size_t)ksteps * 4 * sizeof(int);                       // + the tap-offset table
+                 + (size_t)ksteps * 4 * sizeof(int)                        // + the tap-offset table
+                 + (size_t)8 * 64 * 2 * sizeof(float);                     // + the statistics epilogue's per-wave rows
     auto kern = conv_halo_narrow_in_kernel<T>;
     SGG_LDS_ATTR(kern, 160 * 1024);
     int ntiles = d->N * (d->H / HALO_TH) * (d->W / HALO_TW);
@@ -4702,11 +4839,16 @@ int sgg_conv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w, const f
 }
 
 // Pixel chunks per image of the (sum, sumsq) rows sgg_conv2d_fwd_stats() emits; 0 = this shape has no such epilogue
-size_t sgg_conv2d_fwd_stats_chunks(const sgg_conv_desc* d) {
+static size_t halo3_fwd_stats_chunks(const sgg_conv_desc* d) {           // the LDS-resident 3x3 kernel: a row per (2 x 128 tile, tile row)
     if (!desc_ok(d) || d->dtype != SGG_BF16) return 0;
     ConvArgs a = make_args(d, nullptr, nullptr, nullptr, nullptr, SGG_ACT_NONE, 0.f);
     if (plan_gemm(d, MODE_FWD).ksplit > 1 || !halo3_ok(a, MODE_FWD, true)) return 0;
     return (size_t)(d->H / 2) * (d->W / H3_TW) * 2;
+}
+size_t sgg_conv2d_fwd_stats_chunks(const sgg_conv_desc* d) {
+    if (!desc_ok(d) || d->dtype != SGG_BF16) return 0;
+    if (NI_WIDE && halo_narrow_in_ok(d, d->C, d->K)) return (size_t)(d->H / HALO_TH) * (d->W / HALO_TW);   // the stem: a row per 16 x 32 tile
+    return halo3_fwd_stats_chunks(d);
 }
 
 int sgg_conv2d_fwd_stats(const sgg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* partial,
@@ -4715,6 +4857,7 @@ int sgg_conv2d_fwd_stats(const sgg_conv_desc* d, const void* x, const void* w, c
     if (sgg_conv2d_fwd_stats_chunks(d) == 0) return SGG_EUNSUPPORTED;
     ConvArgs a = make_args(d, x, w, bias, y, SGG_ACT_NONE, 0.f);
     a.stats = partial;
+    if (halo_narrow_in_ok(d, d->C, d->K)) return launch_halo_narrow_in<bf16>(d, a, 0, (hipStream_t)stream);
     return run_gemm<bf16, MODE_FWD>(d, a, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -4852,7 +4995,7 @@ int sgg_conv2d_fwd_stats_pair(const sgg_conv_desc* d, const void* x, const void*
 // x_stats its (mean, rstd) (sgg_instnorm_finalize), and the normalised tensor comes out in x_norm as a by-product.
 int sgg_conv2d_fwd_normload_supported(const sgg_conv_desc* d) {
     if (!desc_ok(d) || d->dtype != SGG_BF16 || d->pad_mode != SGG_PAD_REFLECT || d->C > H3_NORM_MAXC) return 0;
-    return sgg_conv2d_fwd_stats_chunks(d) != 0;
+    return halo3_fwd_stats_chunks(d) != 0;
 }
 int sgg_conv2d_fwd_stats_normload(const sgg_conv_desc* d, const void* x_raw, const float* x_stats, const float* x_gamma, const float* x_beta,
                                   const float* x_gamma2, const float* x_beta2, void* x_norm, const void* w, const float* bias,
@@ -5008,6 +5151,28 @@ int sgg_deconv2d_fwd(const sgg_conv_desc* d, const void* x, const void* w, const
     ConvArgs a = make_args(d, x, w, bias, y, act, leak);
     return d->dtype == SGG_BF16 ? run_gemm<bf16, MODE_DGRAD>(d, a, ws, ws_bytes, (hipStream_t)stream)
                                 : run_gemm<float, MODE_DGRAD>(d, a, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// Conv2DTranspose forward that also emits the per-chunk (sum, sumsq) rows of its stored output for the instance norm behind it
+// (module.py:254-260): one row per (image, 16 x 64 output-pixel tile) from the stride-2 halo kernel's epilogue.
+size_t sgg_deconv2d_fwd_stats_chunks(const sgg_conv_desc* d) {
+    if (!desc_ok(d) || d->dtype != SGG_BF16 || d->pad_mode != SGG_PAD_ZERO || !S2_WIDE) return 0;
+    ConvArgs a = make_args(d, nullptr, nullptr, nullptr, nullptr, SGG_ACT_NONE, 0.f);
+    if (!s2halo_ok(a, true)) return 0;
+    return (size_t)(d->Ho / S2_TI) * (d->Wo / S2_TJ);
+}
+int sgg_deconv2d_fwd_stats(const sgg_conv_desc* d, const void* x, const void* w, const float* bias, const void* w2, const float* bias2, int nsplit,
+                           void* y, float* partial, void* ws, size_t ws_bytes, void* stream) {
+    (void)ws; (void)ws_bytes;
+    if (!desc_ok(d) || !x || !w || !y || !partial) return SGG_EINVAL;
+    if (sgg_deconv2d_fwd_stats_chunks(d) == 0) return SGG_EUNSUPPORTED;
+    ConvArgs a = make_args(d, x, w, bias, y, SGG_ACT_NONE, 0.f);
+    a.stats = partial;
+    if (w2) {
+        if (nsplit <= 0 || nsplit >= d->N) return SGG_EINVAL;
+        a.wmat2 = (const char*)w2; a.bias2 = bias2; a.nsplit = nsplit;
+    }
+    return launch_s2halo(a, (hipStream_t)stream);
 }
 
 int sgg_deconv2d_bwd_data(const sgg_conv_desc* d, const void* dy, const void* w, void* dx, void* ws, size_t ws_bytes, void* stream) {

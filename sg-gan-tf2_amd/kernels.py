@@ -99,7 +99,7 @@ class ConvGeom:
         self.ws_wgrad = int(A.lib().sgg_conv2d_bwd_weight_workspace(C.byref(desc)))
         L = A.lib()
         # pixel chunks of the (sum, sumsq) rows the forward conv can emit for a following instance norm (0: it cannot)
-        self.stats_chunks = 0 if is_deconv else int(L.sgg_conv2d_fwd_stats_chunks(C.byref(desc)))
+        self.stats_chunks = int((L.sgg_deconv2d_fwd_stats_chunks if is_deconv else L.sgg_conv2d_fwd_stats_chunks)(C.byref(desc)))
         # the weight gradients of two applications of the layer can share one launch (cycle step)
         self.wgrad_pair = (not is_deconv) and bool(L.sgg_conv2d_bwd_weight_pair_supported(C.byref(desc)))
         # chunks of the norm-backward partial sums the data gradient can emit for the norm that consumes dx (0: it cannot)
@@ -431,6 +431,21 @@ def deconv_fwd(g: ConvGeom, x, w_dgrad, bias, act=A.ACT_NONE, leak=0.0, out=None
     ws = workspace(g.ws_fwd, x.device) if g.ws_fwd else None
     A.check(A.lib().sgg_deconv2d_fwd(C.byref(g.desc), _p(x), _p(w_dgrad), _p(bias), _p(y), act, leak, _p(ws), g.ws_fwd, _s()), "deconv2d_fwd")
     return y
+
+
+def deconv_fwd_stats(g: ConvGeom, x, w_dgrad, bias, pair=None):
+    """Conv2DTranspose forward (no activation) + the per-chunk (sum, sumsq) rows of its output for the instance norm behind it.
+    pair = (w_dgrad2, bias2, nsplit): `g` describes a stacked batch of two networks, images >= nsplit use the second weight set."""
+    assert tuple(x.shape) == g.x_shape and g.is_deconv and g.stats_chunks > 0
+    y = torch.empty(g.y_shape, dtype=x.dtype, device=x.device)
+    partial = torch.empty((g.y_shape[0], g.stats_chunks, g.y_shape[3], 2), dtype=torch.float32, device=x.device)
+    w2, b2, ns = pair if pair is not None else (None, None, 0)
+    pr = _prof("deconv2d_fwd_stats", g)
+    if pr: pr.start()
+    A.check(A.lib().sgg_deconv2d_fwd_stats(C.byref(g.desc), _p(x), _p(w_dgrad), _p(bias), _p(w2), _p(b2), int(ns), _p(y), _p(partial),
+                                           None, 0, _s()), "deconv2d_fwd_stats")
+    if pr: pr.stop()
+    return y, partial
 
 
 def deconv_dgrad(g: ConvGeom, dy, w_fwd, out=None):

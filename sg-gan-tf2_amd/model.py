@@ -31,7 +31,7 @@ def default_args(**over):
              use_lsgan=True, ratio_gan2seg=10, max_size=50, phase="train", dataset_dir="city",
              dtype="bf16", device="cuda", n_blocks=9, seed=19, graph=False, mixed=False, paired=True,
              fuse_in_stats=True, fuse_in_bwd=False, g_buckets=3, keep_tapes=False, group2=True, d_quad=True,
-             checkpoint_blocks=False, use_pool=False, pool_static=False)
+             checkpoint_blocks=False, use_pool=False, pool_static=False, fuse_in_stats_deconv=False, fuse_in_stats_stem=False)
     a.update(over)
     return SimpleNamespace(**a)
 
@@ -109,6 +109,7 @@ class sggan(object):
             net.mixed = self.mixed
             # conv epilogue -> norm statistics (on), data-gradient epilogue -> norm-backward sums (opt-in; module.py)
             net.fuse_in_stats, net.fuse_in_bwd = bool(g("fuse_in_stats", True)), bool(g("fuse_in_bwd", False))
+            net.fuse_in_stats_deconv, net.fuse_in_stats_stem = bool(g("fuse_in_stats_deconv", False)), bool(g("fuse_in_stats_stem", False))
             net.group2 = bool(g("group2", True))
             # activation checkpointing (BASELINE.json configs[4]): the generators keep each residual block's input only and
             # re-run the block (module.py:208-217) in backward -- bitwise the same gradients, + 2 conv forwards per block

@@ -231,6 +231,12 @@ def plan_buckets(P, unit_names, n_buckets):
 # opt-in of the one-network-at-a-time sequencing; it has no paired form.
 FUSE_CONV_IN_STATS = True
 FUSE_CONV_IN_BWD = False
+# Round 4: the same statistics epilogue exists for the transposed layers (sgg_deconv2d_fwd_stats: the stride-2 halo kernel's own STATS build)
+# and for the stem (sgg_conv2d_fwd_stats on the narrow-input kernel).  Both are parity-tested and OFF: in the cycle step the transposed
+# layers' epilogue costs more than the 152 us of statistics passes it removes (-0.8 % on the step: that kernel has no registers to
+# spare: 32 spilled VGPRs + a second pass over the accumulators), the stem's is neutral (profiles/r04_stats_epilogues.txt).
+FUSE_DECONV_IN_STATS = False
+FUSE_STEM_IN_STATS = False
 
 
 class _ConvUnit:
@@ -292,7 +298,7 @@ class _ConvUnit:
         g = self.geom(x)
         wf, wd = self.packed(x.dtype)
         fused_act = A.ACT_NONE if self.norm else self.act
-        if self.kind == "conv" and self.norm and g.stats_chunks and self.net.fuse_in_stats:
+        if self.kind == "conv" and self.norm and g.stats_chunks and self.net.fuse_in_stats and (self.R != 7 or self.net.fuse_in_stats_stem):
             # the conv's epilogue emits the norm's per-chunk sums: the norm skips its own pass over the tensor
             xc, part = K.conv_fwd_stats(g, x, wf, P.p(n + "_b"))
             if record_only:
@@ -300,6 +306,11 @@ class _ConvUnit:
             y, stats = K.instnorm_fwd_partial(xc, part, P.p(n + "_g"), P.p(n + "_beta"), residual, self.net.eps, self.act, self.leak)
             return y, (g, x, xc, stats)
         assert out is None or not self.norm
+        if self.kind == "deconv" and self.norm and g.stats_chunks and self.net.fuse_in_stats and self.net.fuse_in_stats_deconv:
+            # Conv2DTranspose + InstanceNormalization (module.py:254-260): the stride-2 halo kernel's epilogue emits the norm's sums too
+            xc, part = K.deconv_fwd_stats(g, x, wd, P.p(n + "_b"))
+            y, stats = K.instnorm_fwd_partial(xc, part, P.p(n + "_g"), P.p(n + "_beta"), residual, self.net.eps, self.act, self.leak)
+            return y, (g, x, xc, stats)
         if self.kind == "conv":
             xc = K.conv_fwd(g, x, wf, P.p(n + "_b"), fused_act, self.leak, out=out)
         else:
@@ -393,6 +404,7 @@ class _Net:
         # kernel supports it (the residual chain) -- see sgg_conv2d_bwd_data_mixed in include/sggan.h
         self.mixed = False
         self.fuse_in_stats, self.fuse_in_bwd = FUSE_CONV_IN_STATS, FUSE_CONV_IN_BWD
+        self.fuse_in_stats_deconv, self.fuse_in_stats_stem = FUSE_DECONV_IN_STATS, FUSE_STEM_IN_STATS
         self.group2 = True           # lockstep pairs: both networks' generic convolutions in one grouped launch (sgg_*_group2)
         # activation checkpointing (BASELINE.json configs[4]): a generator keeps only each residual block's INPUT and re-runs
         # the block's two convs + norms in backward (Generator.forward / _block_records)
@@ -667,7 +679,7 @@ class _PairUnit:
             y, stats = K.instnorm_fwd_partial_pair(xc, part, PA.p(na + "_g"), PA.p(na + "_beta"), PB.p(nb + "_g"), PB.p(nb + "_beta"), n,
                                                    residual, ua.net.eps, ua.act, ua.leak)
             return y, (g, x, xc, stats)
-        if ua.kind == "conv" and ua.norm and g.stats_chunks and ua.net.fuse_in_stats:
+        if ua.kind == "conv" and ua.norm and g.stats_chunks and ua.net.fuse_in_stats and (ua.R != 7 or ua.net.fuse_in_stats_stem):
             xc = torch.empty((2 * n,) + tuple(g.y_shape[1:]), dtype=x.dtype, device=x.device)
             part = torch.empty((2 * n, g.stats_chunks, g.y_shape[3], 2), dtype=torch.float32, device=x.device)
             for u, sl in halves:
@@ -676,6 +688,15 @@ class _PairUnit:
             y, stats = K.instnorm_fwd_partial_pair(xc, part, PA.p(na + "_g"), PA.p(na + "_beta"), PB.p(nb + "_g"), PB.p(nb + "_beta"), n,
                                                    residual, ua.net.eps, ua.act, ua.leak)
             return y, (g, x, xc, stats)
+        if ua.kind == "deconv" and ua.norm and ua.net.fuse_in_stats and ua.net.fuse_in_stats_deconv and ua.net.group2:
+            gs = ua.geom(x)                                    # the stacked batch: per-image weights in the stride-2 halo kernel
+            if gs.stats_chunks:
+                _, wda = ua.packed(x.dtype)
+                _, wdb = ub.packed(x.dtype)
+                xc, part = K.deconv_fwd_stats(gs, x, wda, PA.p(na + "_b"), pair=(wdb, PB.p(nb + "_b"), n))
+                y, stats = K.instnorm_fwd_partial_pair(xc, part, PA.p(na + "_g"), PA.p(na + "_beta"), PB.p(nb + "_g"), PB.p(nb + "_beta"), n,
+                                                       residual, ua.net.eps, ua.act, ua.leak)
+                return y, (g, x, xc, stats)
         # every other convolution: ONE grouped launch for both networks (sgg_*_group2: each network's call as its own group of
         # blocks -- bit-identical to two calls; the discriminators' small maps are latency bound, two half-size launches cost twice)
         wfa, wda = ua.packed(x.dtype)

@@ -141,6 +141,34 @@ def test_conv_fwd_stats_epilogue(sg, shape):
     assert g2.stats_chunks == 0
 
 
+def test_stem_conv_fwd_stats_epilogue(sg):
+    """The generator stem (7x7 REFLECT, 3(8) -> 64 channels, module.py:230-233) through sgg_conv2d_fwd_stats: the narrow-input kernel's
+    16-byte-store epilogue also emits one (sum, sumsq) row per (image, 16 x 32 tile).  Output bit-identical to the plain forward; rows add
+    up to the sums of the stored output; the norm fed with them matches the norm that makes its own pass."""
+    from sggan_amd import kernels as K, _abi as A
+    N, H, W = 2, 32, 64
+    rng = np.random.default_rng(9)
+    x = torch.zeros((N, H, W, 8), dtype=torch.bfloat16, device="cuda")
+    x[..., :3] = dev(rng.uniform(0, 1, (N, H, W, 3)), torch.bfloat16)
+    w = dev(rng.standard_normal((7, 7, 3, 64)) / np.sqrt(49 * 3))
+    b = dev(rng.standard_normal(64))
+    g = K.conv_geom(N, H, W, 8, 64, 7, 7, 1, "VALID", 3, torch.bfloat16)
+    assert g.stats_chunks == (H // 16) * (W // 32) and not g.pair_ok and not g.normload_ok
+    wf, _ = K.pack_weights(w, 8, 64, torch.bfloat16)
+    y0 = K.conv_fwd(g, x, wf, b)
+    y1, part = K.conv_fwd_stats(g, x, wf, b)
+    assert torch.equal(y0, y1)
+    yf = y1.float().cpu().numpy().astype(np.float64)
+    got = part.cpu().numpy().astype(np.float64).sum(axis=1)
+    s1, s2 = yf.sum(axis=(1, 2)), (yf * yf).sum(axis=(1, 2))
+    assert np.abs(got[..., 0] - s1).max() < 1e-4 * max(1.0, np.abs(s1).max()) + 1e-2
+    assert np.abs(got[..., 1] - s2).max() < 1e-4 * s2.max()
+    gam, bet = dev(1 + 0.2 * rng.standard_normal(64)), dev(0.2 * rng.standard_normal(64))
+    za, sa = K.instnorm_fwd(y1, gam, bet, None, 1e-3, A.ACT_RELU)
+    zb, sb = K.instnorm_fwd_partial(y1, part, gam, bet, None, 1e-3, A.ACT_RELU)
+    assert (sa - sb).abs().max().item() < 1e-4 and (za.float() - zb.float()).abs().max().item() < 2e-2
+
+
 @pytest.mark.parametrize("pad,act", [("REFLECT-1", "relu"), ("SAME", None)], ids=["reflect_relu", "zero_none"])
 def test_conv_dgrad_norm_bwd_epilogue(sg, pad, act):
     """conv data gradient + instance-norm-backward partial sums in its epilogue (sgg_conv2d_bwd_data_stats): dx is
@@ -220,6 +248,47 @@ def test_deconv2d_fwd_bwd(sg, case, dtype):
     close(tx.grad.detach().float().cpu().numpy(), vx.g, dtype, "dx")
     close(tw.grad.detach().cpu().numpy(), vw.g, dtype, "dw")
     close(tb.grad.detach().cpu().numpy(), vb.g, dtype, "db")
+
+
+@pytest.mark.parametrize("case", [("d2_like", 128, 64, 8, 32, 2), ("d1_like_two_channel_tiles", 256, 128, 16, 64, 1), ("pair", 128, 64, 16, 32, 4)],
+                         ids=lambda c: c[0])
+def test_deconv_fwd_stats_epilogue(sg, case):
+    """Conv2DTranspose forward + instance-norm statistics epilogue (sgg_deconv2d_fwd_stats, module.py:254-260): the output is
+    bit-identical to the plain forward (for a stacked pair: to the two networks' plain forwards), the per-chunk (sum, sumsq) rows
+    -- one per 16 x 64 output-pixel tile -- add up to the sums of the STORED bf16 output, and the norm fed with them matches the norm
+    that makes its own statistics pass."""
+    from sggan_amd import kernels as K, _abi as A
+    name, Ci, Co, H, W, N = case
+    rng = np.random.default_rng(5)
+    x = dev(rng.standard_normal((N, H, W, Ci)), torch.bfloat16)
+    mk = lambda: (dev(rng.standard_normal((3, 3, Co, Ci)) / np.sqrt(9 * Ci)), dev(rng.standard_normal(Co)))
+    (w, b), (w2, b2) = mk(), mk()
+    g = K.deconv_geom(N, H, W, Ci, Co, 3, 3, 2, torch.bfloat16)
+    assert g.stats_chunks == (H // 8) * (W // 32)
+    _, wd = K.pack_weights(w, Co, Ci, torch.bfloat16)       # (kh,kw,out,in) IS the HWIO kernel of the equivalent conv: C = out, K = in
+    _, wd2 = K.pack_weights(w2, Co, Ci, torch.bfloat16)
+    if name == "pair":
+        h = N // 2
+        gh = K.deconv_geom(h, H, W, Ci, Co, 3, 3, 2, torch.bfloat16)
+        y0 = torch.cat([K.deconv_fwd(gh, x[:h], wd, b), K.deconv_fwd(gh, x[h:], wd2, b2)])
+        y1, part = K.deconv_fwd_stats(g, x, wd, b, pair=(wd2, b2, h))
+    else:
+        y0 = K.deconv_fwd(g, x, wd, b)
+        y1, part = K.deconv_fwd_stats(g, x, wd, b)
+    assert torch.equal(y0, y1)
+    yf = y1.float().cpu().numpy().astype(np.float64)
+    got = part.cpu().numpy().astype(np.float64).sum(axis=1)                   # (N, Co, 2)
+    s1, s2 = yf.sum(axis=(1, 2)), (yf * yf).sum(axis=(1, 2))
+    assert np.abs(got[..., 0] - s1).max() < 1e-4 * max(1.0, np.abs(s1).max()) + 1e-2
+    assert np.abs(got[..., 1] - s2).max() < 1e-4 * s2.max()
+    gam, bet = dev(1 + 0.2 * rng.standard_normal(Co)), dev(0.2 * rng.standard_normal(Co))
+    za, sa = K.instnorm_fwd(y1, gam, bet, None, 1e-3, A.ACT_RELU)
+    zb, sb = K.instnorm_fwd_partial(y1, part, gam, bet, None, 1e-3, A.ACT_RELU)
+    assert (sa - sb).abs().max().item() < 1e-4
+    assert (za.float() - zb.float()).abs().max().item() < 2e-2
+    # shapes the stride-2 halo kernel does not take report 0 chunks
+    assert K.deconv_geom(N, 5, 7, Ci, Co, 3, 3, 2, torch.bfloat16).stats_chunks == 0
+    assert K.deconv_geom(N, H, W, Ci, Co, 3, 3, 2, torch.float32).stats_chunks == 0
 
 
 @pytest.mark.parametrize("dtype", DT, ids=["f32", "bf16"])

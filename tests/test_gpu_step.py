@@ -402,7 +402,8 @@ def test_fused_paths_match_unfused_at_bench_width(sg):
             m.real_B, m.seg_B, m.mask_B = b
             m.train_step()
             gl, dl = m.losses()
-            # 2 generators x 2 applications x 2 blocks x 2 convs = 16 res convs forward; every one of them backward
+            # 2 generators x 2 applications x 2 blocks x 2 convs = 16 res convs forward (the stem's and the transposed layers' statistics
+            # epilogues of round 4 are opt-in and off); every one of them backward
             assert calls["fwd"] == (16 if fuse_fwd else 0) and calls["bwd"] == (16 if fuse_bwd else 0)
             assert calls["pair"] == (8 if pair else 0)
             return gl, dl, [n.P.grad.clone() for n in m.networks()]

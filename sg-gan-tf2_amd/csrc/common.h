@@ -146,6 +146,12 @@ __device__ inline void dma16_to_lds(const void* gsrc, __attribute__((address_spa
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m) : "memory", "m0");
 }
 
+// ... with the streaming (nt) cache policy: operand bytes nobody reads again soon
+__device__ inline void dma16_to_lds_nt(const void* gsrc, __attribute__((address_space(3))) void* lds_wave_base) {
+    const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(gsrc), "s"(m) : "memory", "m0");
+}
+
 // the same with the address as a UNIFORM 64-bit base (an SGPR pair) + a 32-bit per-lane byte offset: no 64-bit VGPR address
 // per instruction (the bases of the pieces of one tile differ by scalars -- SALU adds instead of per-lane 64-bit VALU adds,
 // and nothing for hipcc to hoist into registers across the main loop)

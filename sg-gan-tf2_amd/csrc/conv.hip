@@ -798,6 +798,9 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a_in) 
 #ifndef SGG_NT_ADDEND
 #define SGG_NT_ADDEND 0         // 1: the 3x3 halo data gradient reads its skip-gradient addend (its last use) with the streaming cache policy
 #endif
+#ifndef H3_NT
+#define H3_NT 0          // streaming (nt) LDS-DMA of the halo rows: 1 forward (x), 2 data gradient (dy)
+#endif
 #ifndef H3_STAGGER
 #define H3_STAGGER 0                                   // 1: waves of one half run half a tile behind their SIMD partners (main loop header).  OFF: forward +1 % at best, data gradient spills (profiles/r04_persistent_halo_gemm.txt)
 #endif
@@ -1012,7 +1015,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
                 dma16_to_lds_s(rowp, (uint32_t)(wi * SC * 2 + (schunk << 4)), ldst);
             } else {
                 const char* src = ok ? rowp + (size_t)wi * SC * 2 + (schunk << 4) : zero;
-                dma16_to_lds(src, ldst);
+                if (H3_NT & (MODE == MODE_FWD ? 1 : 2)) dma16_to_lds_nt(src, ldst); else dma16_to_lds(src, ldst);
             }
         }
     };
@@ -4228,6 +4231,9 @@ struct W9Args {
 // already selects the half line, bits 1 and 3 pick one of the four 32-byte column pairs.
 __device__ inline int w9_xkey(int row) { return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1; }
 
+#ifndef W9_NT
+#define W9_NT 0          // streaming (nt) LDS-DMA of the operands: 1 the x halo (saved forward activations: their last use), 2 the dy tiles
+#endif
 __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages of { X halo [4][72][128 B], DY [128][256 B] }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar
@@ -4271,7 +4277,8 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
             const int key = wg2_key<bf16>(px) & 15;
             const int trow = px >> 6, tcol = px & 63;
             const char* src = dys + ((((size_t)n * a.H + h0 + trow) * a.W + w0 + tcol) * a.K + n0) * 2 + ((pos ^ key) << 4);
-            dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sD + d * 1024));
+            if (W9_NT & 2) dma16_to_lds_nt(src, (__attribute__((address_space(3))) void*)(sD + d * 1024));
+            else dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sD + d * 1024));
         }
         // x halo: 36 wave-instructions of 8 pixels x 128 B (row k = q / 9, column group q % 9); wave w issues w, w+8, ...
 #pragma unroll
@@ -4288,7 +4295,8 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_halo_kernel(W9Args a) {
                 wi = wi < 0 ? -wi : (wi >= a.W ? 2 * (a.W - 1) - wi : wi);
             } else ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
             const char* src = ok ? xs + ((((size_t)n * a.H + hi) * a.W + wi) * a.C + c0) * 2 + ((pos ^ key) << 4) : zero;
-            dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sX + (k * W9_PITCH + cg * 8) * 128));
+            if (W9_NT & 1) dma16_to_lds_nt(src, (__attribute__((address_space(3))) void*)(sX + (k * W9_PITCH + cg * 8) * 128));
+            else dma16_to_lds(src, (__attribute__((address_space(3))) void*)(sX + (k * W9_PITCH + cg * 8) * 128));
         }
     };
 

@@ -126,6 +126,7 @@ class sggan(object):
         self.use_graph = bool(g("graph", False))
         self._program = None
         self._static_in = {}
+        self._stack_bufs = {}                       # persistent stacked-batch buffers of the step (_stacked)
 
     # ------------------------------------------------------------------ data parallel (new capability)
     def enable_data_parallel(self, process_group=None):
@@ -276,7 +277,7 @@ class sggan(object):
         """A persistent device buffer for one of the step's stacked batches ([real_A; real_B], the discriminators' stacked input
         and masks): inputs are converted straight into its slices and the generators' last layer writes the fakes into it, so
         the step concatenates nothing."""
-        bufs = self.__dict__.setdefault("_stack_bufs", {})
+        bufs = self._stack_bufs
         buf = bufs.get(key)
         if buf is None or tuple(buf.shape) != tuple(shape) or buf.dtype != dtype:
             buf = bufs[key] = torch.empty(tuple(shape), dtype=dtype, device=self.device)

@@ -798,6 +798,9 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a_in) 
 #ifndef SGG_NT_ADDEND
 #define SGG_NT_ADDEND 0         // 1: the 3x3 halo data gradient reads its skip-gradient addend (its last use) with the streaming cache policy
 #endif
+#ifndef H3_LATE_HALO
+#define H3_LATE_HALO 0   // 1: halo-row DMAs by the non-issuer waves after their MFMAs, waited for one tile later (main loop).  OFF: 2-3.5 % slower (profiles/r04_persistent_halo_gemm.txt item 7)
+#endif
 #ifndef H3_NT
 #define H3_NT 0          // streaming (nt) LDS-DMA of the halo rows: 1 forward (x), 2 data gradient (dy)
 #endif
@@ -1210,6 +1213,21 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
     auto main_loop = [&](auto lag_c) {
         constexpr bool LAG = decltype(lag_c)::value;
         u32x4 cw[NI], cp[MI];                            // LAG: k-step 1's weight / pixel fragments of the tile before
+        // LATE_HALO: the halo rows (and patches) are issued by the waves that issue no weight DMAs, AFTER their MFMAs -- in the ~1 200
+        // cycles they otherwise wait at the barrier for their SIMD partners, whose serial path (weight DMAs, then 64 MFMAs) paces the
+        // tile -- and waited for one tile LATER with a counted vmcnt (a row is first read three or more tiles after its issue), so
+        // that their landing time is on nobody's path.  (Round 2 tried the placement with a full drain in the same tile: 2-3 % slower.)
+        constexpr bool LATE_HALO = H3_LATE_HALO && !NORM && !LAG && !STAG;
+        auto issue_halo = [&](int vw) -> int {            // returns the number of halo rows issued this tile (0 .. 2); row 0 brings the patch
+            int rows = 0;
+            if (tap == 0 && chunk > 0) { load_halo_row(cur, 2, chunk, vw, 4, lane); ++rows; }
+            if (tap == 3) {
+                if (chunk > 0) { load_halo_row(cur, 3, chunk, vw, 4, lane); ++rows; }
+                if (chunk + 1 < nchunk) { load_halo_row(cur, 0, chunk + 1, vw, 4, lane); load_patch(cur, chunk + 1, vw, 4, lane); ++rows; }
+            }
+            if (tap == 6 && chunk + 1 < nchunk) { load_halo_row(cur, 1, chunk + 1, vw, 4, lane); ++rows; }
+            return rows;
+        };
         for (int t = 0; t < ntiles; ++t) {
             H3_STAMP(0);
             if constexpr (LAG) {
@@ -1238,14 +1256,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
                     if (ntap == 9) { ntap = 0; ++nchk; }
                     if (t + 1 < ntiles) load_w(cur, (t + 1) & 1, nchk, MODE == MODE_FWD ? ntap : 8 - ntap, vw, 4, lane);
                 }
-                if ((wave >> 2) == H3_HALO_HALF) {             // the halo rows (17 instructions each, ~1 row per tile on average)
-                    if (tap == 0 && chunk > 0) load_halo_row(cur, 2, chunk, vw, 4, lane);
-                    if (tap == 3) {
-                        if (chunk > 0) load_halo_row(cur, 3, chunk, vw, 4, lane);
-                        if (chunk + 1 < nchunk) { load_halo_row(cur, 0, chunk + 1, vw, 4, lane); load_patch(cur, chunk + 1, vw, 4, lane); }
-                    }
-                    if (tap == 6 && chunk + 1 < nchunk) load_halo_row(cur, 1, chunk + 1, vw, 4, lane);
-                }
+                if (!LATE_HALO && (wave >> 2) == H3_HALO_HALF) issue_halo(vw);   // the halo rows (17 instructions each, ~1 row per tile on average)
             }
             H3_STAMP(1);
             const int r = tap / 3, sx = tap - 3 * r;
@@ -1358,6 +1369,27 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
               }
             }
             H3_STAMP(2);
+            if (LATE_HALO && (wave >> 2) != H3_ISSUER_HALF) {
+                // this tile's pieces stay in flight; everything older (the pieces of the tile before) must have landed
+                int mine = 0;
+                if (abl == 0 || abl == 2) {
+                    const int vw = wave & 3;
+                    const bool patch = FOLD && tap == 3 && chunk + 1 < nchunk;
+                    const int rows = issue_halo(vw);
+                    mine = rows * (vw == 0 ? 5 : 4) + (patch ? (vw == 0 ? 2 : 1) : 0);
+                }
+                switch (mine) {
+                    case 0: sgg_wait_vm<0>(); break;
+                    case 4: sgg_wait_vm<4>(); break;
+                    case 5: sgg_wait_vm<5>(); break;
+                    case 7: sgg_wait_vm<7>(); break;
+                    case 8: sgg_wait_vm<8>(); break;
+                    case 9: sgg_wait_vm<9>(); break;
+                    case 10: sgg_wait_vm<10>(); break;
+                    case 12: sgg_wait_vm<12>(); break;
+                    default: sgg_wait_vm<0>(); break;
+                }
+            } else
             if (!NORM || (wave >> 2) == H3_HALO_HALF || (wave >> 2) == H3_ISSUER_HALF) SGG_WAIT_VM0();   // (NORM: the other waves only have stores in flight)
             H3_STAMP(3);
             SGG_WAIT_LGKM0();

@@ -57,28 +57,41 @@ class StepProgram:
     def record(self, body):
         """Capture ``body()`` (kernel launches on the current stream + ``host()`` cut points).  Kernels are NOT executed."""
         assert not self.items, "a StepProgram records once"
-        torch.cuda.synchronize(self.device)
-        side = torch.cuda.Stream(self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):
-            self.capturing = True
-            try:
-                self._open()
-                out = body()
-                self._close()
-            except BaseException:
+        # Cyclic garbage is collected NOW and the collector stays off while the stream is capturing: an earlier model's recorded
+        # program (hipGraphExec objects, events, its private pool) is cyclic garbage, and a collection that happens to run inside
+        # the capture destroys it with HIP calls this thread may not make while capturing -- the process aborts in a destructor
+        # (seen once in the test suite: "Fatal Python error: Aborted ... Garbage-collecting" under test_gpu_dp.py).
+        # torch.cuda.graph() collects before its capture for the same reason.
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            torch.cuda.synchronize(self.device)
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                self.capturing = True
+                try:
+                    self._open()
+                    out = body()
+                    self._close()
+                except BaseException:
+                    self.capturing = False
+                    if self._g is not None:
+                        try:
+                            self._g.capture_end()
+                        except Exception:
+                            pass
+                        self._g = None
+                    self.items = []
+                    raise
                 self.capturing = False
-                if self._g is not None:
-                    try:
-                        self._g.capture_end()
-                    except Exception:
-                        pass
-                    self._g = None
-                self.items = []
-                raise
-            self.capturing = False
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        torch.cuda.synchronize(self.device)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+        finally:
+            if gc_was_on:
+                gc.enable()
         return out
 
     def host(self, fn):

@@ -479,7 +479,10 @@ def bias_grad_group2(dy, db, db2, accumulate=False):
     P = dy.numel() // Cp // 2
     need = 2 * int(A.lib().sgg_bias_grad_workspace(P, Cp))
     ws = workspace(need, dy.device)
+    pr = _prof("bias_grad_group2", (P, Cp))
+    if pr: pr.start()
     A.check(A.lib().sgg_bias_grad_group2(_p(dy), _p(db), _p(db2), P, Cp, db.numel(), int(accumulate), dt(dy), _p(ws), ws.numel(), _s()), "bias_grad_group2")
+    if pr: pr.stop()
 
 
 # ----------------------------------------------------------------------------- instance norm / activations

@@ -798,6 +798,9 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_glds_kernel(ConvArgs a_in) 
 #ifndef SGG_NT_ADDEND
 #define SGG_NT_ADDEND 0         // 1: the 3x3 halo data gradient reads its skip-gradient addend (its last use) with the streaming cache policy
 #endif
+#ifndef H3_EARLY_FRAGS
+#define H3_EARLY_FRAGS 0 // 1: issuer waves put their first fragment reads of the tile in flight BEFORE the tile's DMA issue (main loop).  OFF: data gradient 3 % slower, forward equal (profiles/r04_persistent_halo_gemm.txt item 8)
+#endif
 #ifndef H3_LATE_HALO
 #define H3_LATE_HALO 0   // 1: halo-row DMAs by the non-issuer waves after their MFMAs, waited for one tile later (main loop).  OFF: 2-3.5 % slower (profiles/r04_persistent_halo_gemm.txt item 7)
 #endif
@@ -1249,15 +1252,22 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
             // their MFMAs.  (Not the same as splitting each wave's issue in time: waves 4-7 issuing their own share half way
             // through the tile measured 7 % slower; waves 0-3 issuing the halo rows, or 2-4 of the 8 weight DMAs per SIMD pair,
             // AFTER their MFMAs -- in the ~1 000 cycles they wait at the barrier -- measured 2-3 % slower.)
-            if (abl == 0 || abl == 2) {
-                const int vw = wave & 3;
-                if ((wave >> 2) == H3_ISSUER_HALF) {           // the weight tile: 8 DMA instructions per issuer wave and tile
-                    int ntap = tap + 1, nchk = chunk;
-                    if (ntap == 9) { ntap = 0; ++nchk; }
-                    if (t + 1 < ntiles) load_w(cur, (t + 1) & 1, nchk, MODE == MODE_FWD ? ntap : 8 - ntap, vw, 4, lane);
+            // EARLY_FRAGS: an issuer wave first puts its OWN first fragment reads (4 weight + GJ pixel fragments of this tile, landed since
+            // the last barrier) in flight and issues its DMAs behind them, so that its first MFMA group does not start with an LDS round
+            // trip after ~1 000 cycles of DMA issue -- the issuer's serial path paces the tile.
+            constexpr bool EARLY_FRAGS = H3_EARLY_FRAGS && !LAG && !NORM;
+            auto issue_dmas = [&]() {
+                if (abl == 0 || abl == 2) {
+                    const int vw = wave & 3;
+                    if ((wave >> 2) == H3_ISSUER_HALF) {           // the weight tile: 8 DMA instructions per issuer wave and tile
+                        int ntap = tap + 1, nchk = chunk;
+                        if (ntap == 9) { ntap = 0; ++nchk; }
+                        if (t + 1 < ntiles) load_w(cur, (t + 1) & 1, nchk, MODE == MODE_FWD ? ntap : 8 - ntap, vw, 4, lane);
+                    }
+                    if (!LATE_HALO && (wave >> 2) == H3_HALO_HALF) issue_halo(vw);   // the halo rows (17 instructions each, ~1 row per tile on average)
                 }
-                if (!LATE_HALO && (wave >> 2) == H3_HALO_HALF) issue_halo(vw);   // the halo rows (17 instructions each, ~1 row per tile on average)
-            }
+            };
+            if (!EARLY_FRAGS || abl == 2) issue_dmas();
             H3_STAMP(1);
             const int r = tap / 3, sx = tap - 3 * r;
             // halo offset (r, sx) pairs with weight tap (r, sx) forward and with the flipped tap (2-r, 2-sx) = 8 - tap in
@@ -1297,6 +1307,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_gemm_kernel(ConvArgs a) {
                 u32x4 fp[2][GJ];
     #pragma unroll
                 for (int jj = 0; jj < GJ; ++jj) fp[0][jj] = ldP(jj, 0);
+                if constexpr (EARLY_FRAGS) {
+                    __builtin_amdgcn_sched_barrier(0);           // (the eight reads above go out first)
+                    issue_dmas();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
     #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     const int kk = g / GPK, jb = (g % GPK) * GJ;
